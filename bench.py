@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- MLUPS of the 3D Poisson V(2,2) cycle on MI355X, with the smoother's HBM roofline.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[3]): 3D Poisson, 513 points per axis ("512^3"), fp64, native
+9-level hierarchy, analytic RHS of the reference (Grid3D::InitF), v = 0.  One step = one
+VCycle(0, 2, 2) through the C host layer (include/mg_multigrid.h) with the inputs resident in HBM.
+    MLUPS = (v1+v2) * sum_levels (n_l - 2)^3 * steps / seconds          
+roofline: the dominant kernel is the red-black Gauss-Seidel smoother on the finest level; its
+    algorithmic traffic is 3 reals per lattice update per red+black sweep = 24 B/LUP in fp64.
+    `achieved` = algorithmic bytes per launch / average launch duration, measured here with HIP
+    events on the stream the kernel runs on, over a smoother-only timed region.
+cpu_baseline: the oracle's CPU restatement ("port": same loop nest and single thread as the
+    reference) timed on this box's host cores on a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_BPS = 8.0e12  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; about 6.3 TB/s achievable)
+
+
+def level_sizes(n, nlevels):
+    out = []
+    for _ in range(nlevels):
+        out.append(n)
+        n = (n - 1) // 2 + 1
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=513, help="points per axis of the finest grid (2^k+1)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--v1", type=int, default=2)
+    ap.add_argument("--v2", type=int, default=2)
+    ap.add_argument("--smoother-sweeps", type=int, default=20, help="sweeps in the smoother-only roofline region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # control plane only (barrier, max over ranks); data plane is RCCL in libmgx
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import pde_multigrid_amd as P
+
+    dtype = np.float64 if args.dtype == "f64" else np.float32
+    wbytes = np.dtype(dtype).itemsize
+    ctx = P.Context(local_rank)
+    n = args.n
+    mg = P.MultiGrid3D(ctx, [n] * 3, [0, 1, 0, 1, 0, 1], dtype)  # every rank: one full replica (weak scaling)
+    nlev = mg.numGrids
+    sizes = level_sizes(n, nlev)
+    lups_per_cycle = (args.v1 + args.v2) * sum((s - 2) ** 3 for s in sizes)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    def reset():
+        mg.setToValue_v(0, 0.0, True)
+
+    # ---- V-cycle throughput -----------------------------------------------------------
+    reset()
+    for _ in range(args.warmup):
+        mg.VCycle(0, args.v1, args.v2)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mg.VCycle(0, args.v1, args.v2)
+    ctx.sync()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    mlups = world * lups_per_cycle * args.steps / elapsed / 1e6
+
+    # ---- smoother-only region for the roofline (HIP events on the compute stream) -------
+    reset()
+    mg.Relax(0, 2)
+    e0, e1 = ctx.event(), ctx.event()
+    ctx.sync()
+    ctx.record(e0)
+    mg.Relax(0, args.smoother_sweeps)
+    ctx.record(e1)
+    ms = ctx.elapsed_ms(e0, e1)
+    launches = 2 * args.smoother_sweeps  # one launch per colour
+    lups_per_launch = (n - 2) ** 3 / 2.0
+    bytes_per_launch = 3 * wbytes * lups_per_launch  # 24 B/LUP fp64 per red+black sweep, half per colour launch
+    launch_s = ms * 1e-3 / launches
+    achieved = bytes_per_launch / launch_s
+    smoother_mlups = (n - 2) ** 3 * args.smoother_sweeps / (ms * 1e-3) / 1e6
+
+    if rank != 0:
+        return
+
+    out = {
+        "metric": "MLUPS on 3D Poisson 512^3 V-cycle",
+        "value": round(mlups, 1),
+        "unit": "MLUPS",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic (analytic RHS of the reference: f = -3 pi^2 sin(pi x) sin(pi y) sin(pi z), v = 0)",
+        "config": {
+            "workload": "3D Poisson %d^3 points (%d^3 cells), %s, V(%d,%d) cycle, %d levels, 1 replica per GPU"
+                        % (n, n - 1, args.dtype, args.v1, args.v2, nlev),
+            "levels": sizes,
+            "lups_per_cycle": lups_per_cycle,
+            "parallelism": "single GPU" if world == 1 else "%d independent replicas (z-slab decomposition: see DESIGN.md)" % world,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "relax3d_colour_kernel<%s> (finest level, one colour per launch)" % ("double" if wbytes == 8 else "float"),
+            "achieved": round(achieved / 1e9, 1),
+            "peak": HBM_PEAK_BPS / 1e9,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_BPS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "avg_launch_us": round(launch_s * 1e6, 2),
+            "smoother_mlups": round(smoother_mlups, 1),
+        },
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O  # CPU baseline leg only: the checker timed as a reported baseline
+        cn, clev, reps = 257, 6, 3
+        secs = O.time_vcycle3d(cn, clev, args.v1, args.v2, reps, dtype)
+        c_lups = (args.v1 + args.v2) * sum((s - 2) ** 3 for s in level_sizes(cn, clev)) * reps
+        out["cpu_baseline"] = {
+            "value": round(c_lups / secs / 1e6, 2),
+            "unit": "MLUPS",
+            "cores": 1,
+            "kind": "port",
+            "sample": "%d V(%d,%d) cycles, 3D Poisson %d^3 %s, %d levels, oracle CPU restatement (-O2, reference loop nest, "
+                      "1 thread of %d host cores), %.1f s" % (reps, args.v1, args.v2, cn, args.dtype, clev, os.cpu_count() or 0, secs),
+        }
+    print(json.dumps(out))
+    mg.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/* mg_multigrid.h -- C host layer: the reference's Grid{1,2,3}D / MultiGrid{1,2,3}D classes as C
+ * structs + functions, driving the HIP kernels through the thin C-ABI of mgx.h.
+ *
+ * Mirrors, member for member, the public surface of the NOCUDA_TESI reference:
+ *   class Grid3D        N3/Grid3D.h:4-38        -> struct mgGrid3D_<r>
+ *   class MultiGrid3D   N3/MultiGrid3D.h:6-33   -> struct mgMultiGrid3D_<r> + mgMultiGrid3D_<r>_<Method>
+ *   class Grid2D        N2/Grid2D.h:4-33        -> struct mgGrid2D_<r>
+ *   class MultiGrid2D   N2/MultiGrid2D.h:6-37   -> struct mgMultiGrid2D_<r> + ...
+ *   class Grid1D        N1/Grid1D.h:4-26        -> struct mgGrid1D_<r>      (CPU only: "plumbing")
+ *   class MultiGrid1D   N1/MultiGrid1D.h:6-31   -> struct mgMultiGrid1D_<r> (CPU only)
+ * with <r> = f32 (the reference's own type) or f64 (BASELINE.json's GPU configs).
+ *
+ * Same names, same argument meaning, same level-count rule (numGrids = (int)log2(minSize-1),
+ * N3/MultiGrid3D.cpp:33-34; `numGrids` stays a public mutable field that may be lowered
+ * after construction), same cycle control flow (VCycle N3/MultiGrid3D.cpp:623-647,
+ * FullMultiGridVCycle :569-585).  Differences, all at the boundary:
+ *   - every function returns an int status (mgx_status) instead of asserting/aborting;
+ *   - d_v / d_f are device arrays (reference layout: dense, x fastest); h_v / h_f are host
+ *     mirrors filled by *_download_* and pushed by *_upload_*;
+ *   - residual / error scratch is owned by the level and preallocated (the reference mallocs
+ *     both inside every VCycle call and never frees them, N3/MultiGrid3D.cpp:629,638);
+ *   - `residual_mode` selects REF_COMPAT (default; reproduces the 3D residual sign quirk,
+ *     N3/MultiGrid3D.cpp:723) or CORRECT;
+ *   - `fuse` (default 1) runs CalculateResidual+Restrict and Interpolate+ApplyCorrection as
+ *     one kernel each; results are bit-identical to the unfused sequence.
+ * The 1D classes run entirely on the host in C (BASELINE.json configs[0]: CPU path, no GPU).
+ */
+#ifndef MG_MULTIGRID_H
+#define MG_MULTIGRID_H
+
+#include "mgx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_DECLARE(R, real)                                                                              \
+    /* ------------------------------------------------------------------ 3D ------ */                  \
+    typedef struct mgGrid3D_##R {                                                                        \
+        real* h_v; /* host mirror of the approximate solution (NULL until first download/upload) */     \
+        real* h_f; /* host mirror of the right-hand side */                                              \
+        real* d_v; /* device: approximate solution */                                                    \
+        real* d_f; /* device: right-hand side */                                                         \
+        real* d_r; /* device scratch: residual (unfused path) */                                         \
+        real* d_e; /* device scratch: interpolated error (unfused path) */                               \
+        int sizeX, sizeY, sizeZ;                                                                         \
+        int sizeXYZ[3];                                                                                  \
+        real h_x, h_y, h_z;                                                                              \
+        real x_a, x_b, y_a, y_b, z_a, z_b;                                                               \
+    } mgGrid3D_##R;                                                                                      \
+    typedef struct mgMultiGrid3D_##R {                                                                   \
+        mgGrid3D_##R** grids3D;                                                                          \
+        int numGrids;    /* public and mutable like the reference's; 1 <= numGrids <= maxGrids */        \
+        int maxGrids;    /* levels allocated = (int)log2(minSize-1) */                                   \
+        mgx_ctx* ctx;                                                                                    \
+        int residual_mode; /* mgx_residual_mode */                                                       \
+        int fuse;                                                                                        \
+    } mgMultiGrid3D_##R;                                                                                 \
+    int mgMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6],     \
+                                   mgMultiGrid3D_##R** out);                                             \
+    void mgMultiGrid3D_##R##_destroy(mgMultiGrid3D_##R* mg);                                             \
+    int mgMultiGrid3D_##R##_InitV(mgMultiGrid3D_##R* mg, int gridID);                                    \
+    int mgMultiGrid3D_##R##_InitF(mgMultiGrid3D_##R* mg, int gridID);                                    \
+    int mgMultiGrid3D_##R##_Restrict(mgMultiGrid3D_##R* mg, const real* fine, const int fsizeXYZ[3],     \
+                                     real* coarse, const int csizeXYZ[3]);                               \
+    int mgMultiGrid3D_##R##_Interpolate(mgMultiGrid3D_##R* mg, real* fine, const int fsizeXYZ[3],        \
+                                        const real* coarse, const int csizeXYZ[3]);                      \
+    int mgMultiGrid3D_##R##_Relax(mgMultiGrid3D_##R* mg, mgGrid3D_##R* curGrid, int ncycles);            \
+    int mgMultiGrid3D_##R##_setToValue(mgMultiGrid3D_##R* mg, real* grid, const int sizeXYZ[3],          \
+                                       real value, int modifyBoundaries);                                \
+    int mgMultiGrid3D_##R##_CalculateResidual(mgMultiGrid3D_##R* mg, mgGrid3D_##R* fine,                 \
+                                              real** residual);                                          \
+    int mgMultiGrid3D_##R##_ApplyCorrection(mgMultiGrid3D_##R* mg, real* fine, const int fsizeXYZ[3],    \
+                                            const real* error, const int esizeXYZ[3]);                   \
+    int mgMultiGrid3D_##R##_VCycle(mgMultiGrid3D_##R* mg, int gridID, int v1, int v2);                   \
+    int mgMultiGrid3D_##R##_FullMultiGridVCycle(mgMultiGrid3D_##R* mg, int gridID, int v0, int v1,       \
+                                                int v2);                                                 \
+    int mgMultiGrid3D_##R##_upload_v(mgMultiGrid3D_##R* mg, int gridID, const real* host);               \
+    int mgMultiGrid3D_##R##_upload_f(mgMultiGrid3D_##R* mg, int gridID, const real* host);               \
+    int mgMultiGrid3D_##R##_download_v(mgMultiGrid3D_##R* mg, int gridID, real* host);                   \
+    int mgMultiGrid3D_##R##_download_f(mgMultiGrid3D_##R* mg, int gridID, real* host);                   \
+    int mgMultiGrid3D_##R##_ResidualNorm(mgMultiGrid3D_##R* mg, int gridID, double* l2);                 \
+    /* solve(grid, rhs, nlevels): host arrays in the reference layout; grid = initial guess incl.     */ \
+    /* boundary values on input, solution on output; nlevels = 0 -> reference rule; ncycles V(v1,v2)  */ \
+    /* cycles from the given guess, or one FullMultiGridVCycle(v0,v1,v2) when fmg != 0.               */ \
+    int mg3d_solve_##R(mgx_ctx* ctx, real* grid, const real* rhs, const int sizeXYZ[3],                  \
+                       const real range[6], int nlevels, int fmg, int v0, int v1, int v2, int ncycles,   \
+                       int residual_mode);                                                               \
+    /* ------------------------------------------------------------------ 2D ------ */                  \
+    typedef struct mgGrid2D_##R {                                                                        \
+        real* h_v;                                                                                       \
+        real* h_f;                                                                                       \
+        real* d_v;                                                                                       \
+        real* d_f;                                                                                       \
+        real* d_r;                                                                                       \
+        real* d_e;                                                                                       \
+        int sizeX, sizeY;                                                                                \
+        int sizeXY[2];                                                                                   \
+        real h_x, h_y;                                                                                   \
+        real x_a, x_b, y_a, y_b;                                                                         \
+    } mgGrid2D_##R;                                                                                      \
+    typedef struct mgMultiGrid2D_##R {                                                                   \
+        mgGrid2D_##R** grids2D;                                                                          \
+        int numGrids;                                                                                    \
+        int maxGrids;                                                                                    \
+        real matrixA[4];                                                                                 \
+        int sizeA;                                                                                       \
+        int alfa;                                                                                        \
+        mgx_ctx* ctx;                                                                                    \
+        int fuse;                                                                                        \
+    } mgMultiGrid2D_##R;                                                                                 \
+    int mgMultiGrid2D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXY[2], const real range[4],     \
+                                   const real* A, int A_size, int alfa, mgMultiGrid2D_##R** out);        \
+    void mgMultiGrid2D_##R##_destroy(mgMultiGrid2D_##R* mg);                                             \
+    int mgMultiGrid2D_##R##_InitV(mgMultiGrid2D_##R* mg, int gridID);                                    \
+    int mgMultiGrid2D_##R##_InitF(mgMultiGrid2D_##R* mg, int gridID);                                    \
+    int mgMultiGrid2D_##R##_Restrict(mgMultiGrid2D_##R* mg, const real* fine, const int fsizeXY[2],      \
+                                     real* coarse, const int csizeXY[2]);                                \
+    int mgMultiGrid2D_##R##_Interpolate(mgMultiGrid2D_##R* mg, real* fine, const int fsizeXY[2],         \
+                                        const real* coarse, const int csizeXY[2]);                       \
+    int mgMultiGrid2D_##R##_Relax(mgMultiGrid2D_##R* mg, mgGrid2D_##R* curGrid, int ncycles);            \
+    int mgMultiGrid2D_##R##_setToValue(mgMultiGrid2D_##R* mg, real* grid, const int sizeXY[2],           \
+                                       real value, int modifyBoundaries);                                \
+    int mgMultiGrid2D_##R##_CalculateResidual(mgMultiGrid2D_##R* mg, mgGrid2D_##R* fine,                 \
+                                              real** residual);                                          \
+    int mgMultiGrid2D_##R##_ApplyCorrection(mgMultiGrid2D_##R* mg, real* fine, const int fsizeXY[2],     \
+                                            const real* error, const int esizeXY[2]);                    \
+    int mgMultiGrid2D_##R##_VCycle(mgMultiGrid2D_##R* mg, int gridID, int v1, int v2);                   \
+    int mgMultiGrid2D_##R##_FullMultiGridVCycle(mgMultiGrid2D_##R* mg, int gridID, int v0, int v1,       \
+                                                int v2);                                                 \
+    int mgMultiGrid2D_##R##_upload_v(mgMultiGrid2D_##R* mg, int gridID, const real* host);               \
+    int mgMultiGrid2D_##R##_upload_f(mgMultiGrid2D_##R* mg, int gridID, const real* host);               \
+    int mgMultiGrid2D_##R##_download_v(mgMultiGrid2D_##R* mg, int gridID, real* host);                   \
+    int mgMultiGrid2D_##R##_download_f(mgMultiGrid2D_##R* mg, int gridID, real* host);                   \
+    int mg2d_solve_##R(mgx_ctx* ctx, real* grid, const real* rhs, const int sizeXY[2],                   \
+                       const real range[4], const real A[4], int alfa, int nlevels, int fmg, int v0,     \
+                       int v1, int v2, int ncycles);                                                     \
+    /* ------------------------------------------------------------------ 1D (host only) */             \
+    typedef struct mgGrid1D_##R {                                                                        \
+        real* h_v;                                                                                       \
+        real* h_f;                                                                                       \
+        int sizeX;                                                                                       \
+        real h_x;                                                                                        \
+        real x_a, x_b;                                                                                   \
+    } mgGrid1D_##R;                                                                                      \
+    typedef struct mgMultiGrid1D_##R {                                                                   \
+        mgGrid1D_##R** grids1D;                                                                          \
+        int numGrids;                                                                                    \
+        int maxGrids;                                                                                    \
+    } mgMultiGrid1D_##R;                                                                                 \
+    int mgMultiGrid1D_##R##_create(int finestGridSize, const real range[2], mgMultiGrid1D_##R** out);    \
+    void mgMultiGrid1D_##R##_destroy(mgMultiGrid1D_##R* mg);                                             \
+    int mgMultiGrid1D_##R##_Restrict(mgMultiGrid1D_##R* mg, const real* fine, int fsize, real* coarse,   \
+                                     int csize);                                                         \
+    int mgMultiGrid1D_##R##_Interpolate(mgMultiGrid1D_##R* mg, real* fine, int fsize,                    \
+                                        const real* coarse, int csize);                                  \
+    int mgMultiGrid1D_##R##_Relax(mgMultiGrid1D_##R* mg, mgGrid1D_##R* curGrid, int ncycles);            \
+    int mgMultiGrid1D_##R##_setToValue(mgMultiGrid1D_##R* mg, real* grid, int sizeX, real value,         \
+                                       int modifyBoundaries);                                            \
+    int mgMultiGrid1D_##R##_CalculateResidual(mgMultiGrid1D_##R* mg, mgGrid1D_##R* fine,                 \
+                                              real* residual);                                           \
+    int mgMultiGrid1D_##R##_ApplyCorrection(mgMultiGrid1D_##R* mg, real* fine, int fineSize,             \
+                                            const real* error, int errorSize);                           \
+    int mgMultiGrid1D_##R##_VCycle(mgMultiGrid1D_##R* mg, int gridID, int v1, int v2);                   \
+    int mgMultiGrid1D_##R##_FullMultiGridVCycle(mgMultiGrid1D_##R* mg, int gridID, int v0, int v1,       \
+                                                int v2);                                                 \
+    int mg1d_solve_##R(real* grid, const real* rhs, int sizeX, const real range[2], int nlevels,         \
+                       int fmg, int v0, int v1, int v2, int ncycles);
+
+MG_DECLARE(f32, float)
+MG_DECLARE(f64, double)
+
+/* numGrids = (int)log2(minSize - 1)            N3/MultiGrid3D.cpp:33-34 */
+int mg_num_grids(int minSize);
+/* coarse size = ((size-1)/2)+1                 N3/MultiGrid3D.cpp:40-42 */
+int mg_coarse_size(int size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MG_MULTIGRID_H */

@@ -1,0 +1,179 @@
+/* mgx.h -- thin C-ABI over the hand-written HIP (gfx950 / MI355X) multigrid kernels.
+ *
+ * This is the drop-in boundary of the hot path.  The reference
+ * (MisterPup/PDE-MultiGrid, NOCUDA_TESI) has no FFI layer: its boundary is the public
+ * C++ surface of MultiGrid{2,3}D.  Each entry point below replaces one of those member
+ * functions and takes the same arguments as plain pointers and sizes (device pointers
+ * instead of host `float*`; `real` = float or double chosen by the _f32/_f64 suffix;
+ * the grid spacing / range members the reference reads from Grid3D* are passed
+ * explicitly).  The C host layer in include/mg_multigrid.h is the only caller in the
+ * product; tests and bench.py reach it through ctypes.
+ *
+ *   reference member function (file:line)                      replacement
+ *   -------------------------------------------------------    -----------------------------
+ *   MultiGrid3D::Relax            N3/MultiGrid3D.cpp:489-567   mgx3d_relax_{f32,f64}
+ *   MultiGrid3D::CalculateResidual N3/MultiGrid3D.cpp:678-730  mgx3d_residual_*
+ *   MultiGrid3D::Restrict         N3/MultiGrid3D.cpp:50-184    mgx3d_restrict_*
+ *   MultiGrid3D::Interpolate      N3/MultiGrid3D.cpp:186-335   mgx3d_interpolate_*
+ *   MultiGrid3D::ApplyCorrection  N3/MultiGrid3D.cpp:649-676   mgx3d_apply_correction_*
+ *   MultiGrid3D::setToValue       N3/MultiGrid3D.cpp:587-621   mgx3d_set_*
+ *   Grid3D::InitF                 N3/Grid3D.cpp:78-96          mgx3d_init_f_* (host sin tables)
+ *   MultiGrid2D::Relax            N2/MultiGrid2D.cpp:199-273   mgx2d_relax_*
+ *   MultiGrid2D::CalculateResidual N2/MultiGrid2D.cpp:367-408  mgx2d_residual_*
+ *   MultiGrid2D::Restrict         N2/MultiGrid2D.cpp:63-126    mgx2d_restrict_*
+ *   MultiGrid2D::Interpolate      N2/MultiGrid2D.cpp:128-196   mgx2d_interpolate_*
+ *   MultiGrid2D::ApplyCorrection  N2/MultiGrid2D.cpp:343-366   mgx2d_apply_correction_*
+ *   MultiGrid2D::setToValue       N2/MultiGrid2D.cpp:275-292   mgx2d_set_*
+ *   (N3 = NOCUDA_TESI/POISSON_3D(TESI)/, N2 = NOCUDA_TESI/PDE Lyapunov 2D/)
+ *
+ * Fused forms (bit-identical to the two calls they replace):
+ *   CalculateResidual + Restrict   (VCycle, N3/MultiGrid3D.cpp:629-632)  mgx3d_residual_restrict_*
+ *   Interpolate + ApplyCorrection  (VCycle, N3/MultiGrid3D.cpp:638-642)  mgx3d_interpolate_correct_*
+ *
+ * Conventions
+ *   - every function returns an int status (MGX_OK = 0); nothing aborts
+ *     (the reference asserts, N3/MultiGrid3D.cpp:60-62).  mgx_last_error() gives text.
+ *   - arrays are dense, unpadded, x fastest: idx = x + y*sx + z*sx*sy
+ *     (N3/MultiGrid3D.cpp:531); sizes are int[dim] = {sx, sy(, sz)}, each 2^k+1.
+ *   - all `real*` arguments are DEVICE pointers obtained from mgx_malloc unless the
+ *     name starts with host_.
+ *   - kernels run on the context's compute stream; calls are asynchronous with respect
+ *     to the host unless stated; mgx_ctx_sync() waits.
+ *   - one context per host thread; no global state.
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MGX_OK = 0,
+    MGX_ERR_INVALID = 1, /* NULL pointer, bad enum, negative count ...            */
+    MGX_ERR_SIZE = 2,    /* size relation violated (the reference would assert)   */
+    MGX_ERR_HIP = 3,     /* a HIP runtime call failed                             */
+    MGX_ERR_NOMEM = 4,
+    MGX_ERR_RCCL = 5,
+    MGX_ERR_NOGPU = 6    /* no HIP device visible                                 */
+} mgx_status;
+
+/* Residual variants: REF_COMPAT reproduces the reference's
+ * sign quirk ((N-2v-S)/hy2, (D-2v-U)/hz2, N3/MultiGrid3D.cpp:723); CORRECT uses +S, +U. */
+typedef enum { MGX_RESIDUAL_REF_COMPAT = 0, MGX_RESIDUAL_CORRECT = 1 } mgx_residual_mode;
+
+typedef struct mgx_ctx mgx_ctx;
+typedef struct mgx_event mgx_event;
+
+const char* mgx_status_string(int status);
+const char* mgx_last_error(void); /* thread-local, valid until the next failing call */
+void mgx_set_last_error(const char* msg); /* for layers above (include/mg_multigrid.h) */
+const char* mgx_version(void);
+
+/* ---- context / device ------------------------------------------------------------ */
+int mgx_device_count(int* count);
+int mgx_ctx_create(int device, mgx_ctx** out);
+int mgx_ctx_destroy(mgx_ctx* ctx);
+int mgx_ctx_sync(mgx_ctx* ctx);                 /* waits for the compute and comm streams */
+int mgx_ctx_device(const mgx_ctx* ctx, int* device);
+/* raw hipStream_t of the compute stream (for callers that bring their own HIP code) */
+int mgx_ctx_stream(const mgx_ctx* ctx, void** hip_stream);
+
+/* ---- device memory ------------------------------------------------------------------ */
+int mgx_malloc(mgx_ctx* ctx, size_t bytes, void** dptr);
+int mgx_free(mgx_ctx* ctx, void* dptr);
+int mgx_memcpy_h2d(mgx_ctx* ctx, void* dst, const void* host_src, size_t bytes); /* blocking */
+int mgx_memcpy_d2h(mgx_ctx* ctx, void* host_dst, const void* src, size_t bytes); /* blocking */
+int mgx_memcpy_d2d(mgx_ctx* ctx, void* dst, const void* src, size_t bytes);      /* async    */
+int mgx_memset_zero(mgx_ctx* ctx, void* dst, size_t bytes);                      /* async    */
+
+/* ---- timing on the compute stream (HIP events) ------------------------------------ */
+int mgx_event_create(mgx_ctx* ctx, mgx_event** out);
+int mgx_event_destroy(mgx_ctx* ctx, mgx_event* ev);
+int mgx_event_record(mgx_ctx* ctx, mgx_event* ev);
+int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float* ms); /* syncs on stop */
+
+/* ---- operators ------------------------------------------------------------------------
+ * Declared once per real type through MGX_DECLARE_OPS(suffix, real).
+ *
+ * mgx3d_relax: `ncycles` red-black Gauss-Seidel sweeps, in place (one launch per colour).
+ * mgx3d_residual: r = f - A v on the interior (mode selects the sign variant), 0 on the boundary.
+ * mgx3d_restrict: 27-point full weighting, boundary = injection; cn must equal (fn-1)/2+1.
+ * mgx3d_interpolate: trilinear, interior of `fine` only (boundary untouched).
+ * mgx3d_apply_correction: fine += err on the interior.
+ * mgx3d_set: fill; modify_boundaries = 0 leaves the boundary untouched.
+ * mgx3d_residual_restrict: coarse_f = Restrict(CalculateResidual(v, f)) without storing
+ *   the fine residual.
+ * mgx3d_interpolate_correct: v += Interpolate(coarse_v) on the interior.
+ * mgx3d_init_f: f[x,y,z] = (real)(c * tx[x] * ty[y] * tz[z]) evaluated in double, left to
+ *   right (Grid3D::InitF with host-computed sin tables; tables are host pointers).
+ * mgx_norm2: sum of squares of `count` reals in double (wave-wide shuffle reduction +
+ *   one atomic per block); host result, blocking.  An addition: the reference has no norm.
+ */
+#define MGX_DECLARE_OPS(SFX, real)                                                                      \
+    int mgx3d_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3],        \
+                          int ncycles);                                                                 \
+    int mgx3d_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3],       \
+                             const real h[3], int mode);                                                \
+    int mgx3d_restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse,             \
+                             const int cn[3]);                                                          \
+    int mgx3d_interpolate_##SFX(mgx_ctx* ctx, real* fine, const int fn[3], const real* coarse,          \
+                                const int cn[3]);                                                       \
+    int mgx3d_apply_correction_##SFX(mgx_ctx* ctx, real* fine, const int fn[3], const real* err,        \
+                                     const int en[3]);                                                  \
+    int mgx3d_set_##SFX(mgx_ctx* ctx, real* grid, const int n[3], real value, int modify_boundaries);   \
+    int mgx3d_residual_restrict_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[3],       \
+                                      const real h[3], int mode, real* coarse_f, const int cn[3]);      \
+    int mgx3d_interpolate_correct_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,    \
+                                        const int cn[3]);                                               \
+    int mgx3d_init_f_##SFX(mgx_ctx* ctx, real* f, const int n[3], double c, const double* host_tx,      \
+                           const double* host_ty, const double* host_tz);                               \
+    int mgx2d_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[2], const real h[2],        \
+                          const real a[2], const real A[4], int alfa, int ncycles);                     \
+    int mgx2d_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[2],       \
+                             const real h[2], const real a[2], const real A[4], int alfa);              \
+    int mgx2d_restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[2], real* coarse,             \
+                             const int cn[2]);                                                          \
+    int mgx2d_interpolate_##SFX(mgx_ctx* ctx, real* fine, const int fn[2], const real* coarse,          \
+                                const int cn[2]);                                                       \
+    int mgx2d_apply_correction_##SFX(mgx_ctx* ctx, real* fine, const int fn[2], const real* err,        \
+                                     const int en[2]);                                                  \
+    int mgx2d_set_##SFX(mgx_ctx* ctx, real* grid, const int n[2], real value, int modify_boundaries);   \
+    int mgx_norm2_##SFX(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq);
+
+MGX_DECLARE_OPS(f32, float)
+MGX_DECLARE_OPS(f64, double)
+
+/* ---- multi-GPU: z-slab halo exchange over RCCL (xGMI) ------------------------------
+ * One process per GPU.  The unique id is created on rank 0 (mgx_comm_unique_id) and
+ * handed to the other ranks by the launcher (bench.py broadcasts it with
+ * torch.distributed); every rank then calls mgx_comm_init.  All communication runs on the
+ * context's comm stream; mgx_comm_* functions that move planes take care of the
+ * event ordering against the compute stream.
+ */
+#define MGX_UNIQUE_ID_BYTES 128
+int mgx_comm_unique_id(void* host_id_bytes);
+int mgx_comm_init(mgx_ctx* ctx, const void* host_id_bytes, int rank, int nranks);
+int mgx_comm_destroy(mgx_ctx* ctx);
+int mgx_comm_rank(const mgx_ctx* ctx, int* rank, int* nranks);
+/* Exchange ghost planes with the z-neighbours on a non-periodic chain: send `count`
+ * reals from send_down to rank-1 and from send_up to rank+1, receive into recv_down
+ * (from rank-1) and recv_up (from rank+1).  Pointers towards a missing neighbour are
+ * ignored.  elem_bytes = 4 or 8.  Asynchronous on the comm stream: it first waits for
+ * everything enqueued so far on the compute stream; mgx_comm_wait makes the compute
+ * stream wait for the exchange. */
+int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_down, void* recv_down, const void* send_up,
+                           void* recv_up, size_t count, int elem_bytes);
+int mgx_comm_wait(mgx_ctx* ctx);
+/* all-gather `count` reals per rank (agglomeration of a coarse level) and all-reduce one
+ * double (residual norm).  Both enqueue on the comm stream with the same ordering rules. */
+int mgx_comm_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count, int elem_bytes);
+int mgx_comm_allreduce_sum_f64(mgx_ctx* ctx, double* dev_inout, size_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

@@ -1,0 +1,210 @@
+// mgx_core.hip -- context, memory, events, errors behind include/mgx.h.
+#include "mgx_internal.hpp"
+
+namespace mgx {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int workspace(mgx_ctx* ctx, size_t bytes, void** out) {
+    if (ctx->scratch_bytes < bytes) {
+        if (ctx->scratch) {
+            MGX_HIP(hipStreamSynchronize(ctx->compute));
+            MGX_HIP(hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+        }
+        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        MGX_HIP(hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return MGX_OK;
+}
+
+}  // namespace mgx
+
+extern "C" {
+
+const char* mgx_status_string(int s) {
+    switch (s) {
+        case MGX_OK: return "MGX_OK";
+        case MGX_ERR_INVALID: return "MGX_ERR_INVALID";
+        case MGX_ERR_SIZE: return "MGX_ERR_SIZE";
+        case MGX_ERR_HIP: return "MGX_ERR_HIP";
+        case MGX_ERR_NOMEM: return "MGX_ERR_NOMEM";
+        case MGX_ERR_RCCL: return "MGX_ERR_RCCL";
+        case MGX_ERR_NOGPU: return "MGX_ERR_NOGPU";
+    }
+    return "MGX_ERR_UNKNOWN";
+}
+
+const char* mgx_last_error(void) { return mgx::g_err; }
+void mgx_set_last_error(const char* msg) { mgx::set_error("%s", msg ? msg : ""); }
+const char* mgx_version(void) { return "mgx 0.1 (gfx950)"; }
+
+int mgx_device_count(int* count) {
+    MGX_REQUIRE(count, MGX_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        (void)hipGetLastError();
+        return mgx::fail(MGX_ERR_NOGPU, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return MGX_OK;
+}
+
+int mgx_ctx_create(int device, mgx_ctx** out) {
+    MGX_REQUIRE(out, MGX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return mgx::fail(MGX_ERR_NOGPU, "no HIP device visible: the HIP path cannot run (there is no CPU fallback)");
+    }
+    MGX_REQUIRE(device >= 0 && device < n, MGX_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    MGX_HIP(hipSetDevice(device));
+    mgx_ctx* c = new mgx_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming)) != hipSuccess) {
+        delete c;
+        return mgx::fail(MGX_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return MGX_OK;
+}
+
+int mgx_ctx_destroy(mgx_ctx* ctx) {
+    if (!ctx) return MGX_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->rccl_comm) mgx_comm_destroy(ctx);
+    (void)hipStreamSynchronize(ctx->compute);
+    (void)hipStreamSynchronize(ctx->comm);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)hipEventDestroy(ctx->ev_compute);
+    (void)hipEventDestroy(ctx->ev_comm);
+    (void)hipStreamDestroy(ctx->compute);
+    (void)hipStreamDestroy(ctx->comm);
+    delete ctx;
+    return MGX_OK;
+}
+
+int mgx_ctx_sync(mgx_ctx* ctx) {
+    MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_HIP(hipStreamSynchronize(ctx->compute));
+    MGX_HIP(hipStreamSynchronize(ctx->comm));
+    MGX_HIP(hipDeviceSynchronize());
+    return MGX_OK;
+}
+
+int mgx_ctx_device(const mgx_ctx* ctx, int* device) {
+    MGX_REQUIRE(ctx && device, MGX_ERR_INVALID, "NULL argument");
+    *device = ctx->device;
+    return MGX_OK;
+}
+
+int mgx_ctx_stream(const mgx_ctx* ctx, void** hip_stream) {
+    MGX_REQUIRE(ctx && hip_stream, MGX_ERR_INVALID, "NULL argument");
+    *hip_stream = (void*)ctx->compute;
+    return MGX_OK;
+}
+
+int mgx_malloc(mgx_ctx* ctx, size_t bytes, void** dptr) {
+    MGX_REQUIRE(ctx && dptr, MGX_ERR_INVALID, "NULL argument");
+    *dptr = nullptr;
+    if (bytes == 0) return MGX_OK;
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return mgx::fail(MGX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    return MGX_OK;
+}
+
+int mgx_free(mgx_ctx* ctx, void* dptr) {
+    MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    if (!dptr) return MGX_OK;
+    MGX_HIP(hipStreamSynchronize(ctx->compute));
+    MGX_HIP(hipStreamSynchronize(ctx->comm));
+    MGX_HIP(hipFree(dptr));
+    return MGX_OK;
+}
+
+int mgx_memcpy_h2d(mgx_ctx* ctx, void* dst, const void* host_src, size_t bytes) {
+    MGX_REQUIRE(ctx && (bytes == 0 || (dst && host_src)), MGX_ERR_INVALID, "NULL argument");
+    if (!bytes) return MGX_OK;
+    MGX_HIP(hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, ctx->compute));
+    MGX_HIP(hipStreamSynchronize(ctx->compute));
+    return MGX_OK;
+}
+
+int mgx_memcpy_d2h(mgx_ctx* ctx, void* host_dst, const void* src, size_t bytes) {
+    MGX_REQUIRE(ctx && (bytes == 0 || (host_dst && src)), MGX_ERR_INVALID, "NULL argument");
+    if (!bytes) return MGX_OK;
+    MGX_HIP(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, ctx->compute));
+    MGX_HIP(hipStreamSynchronize(ctx->compute));
+    return MGX_OK;
+}
+
+int mgx_memcpy_d2d(mgx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    MGX_REQUIRE(ctx && (bytes == 0 || (dst && src)), MGX_ERR_INVALID, "NULL argument");
+    if (!bytes) return MGX_OK;
+    MGX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->compute));
+    return MGX_OK;
+}
+
+int mgx_memset_zero(mgx_ctx* ctx, void* dst, size_t bytes) {
+    MGX_REQUIRE(ctx && (bytes == 0 || dst), MGX_ERR_INVALID, "NULL argument");
+    if (!bytes) return MGX_OK;
+    MGX_HIP(hipMemsetAsync(dst, 0, bytes, ctx->compute));
+    return MGX_OK;
+}
+
+int mgx_event_create(mgx_ctx* ctx, mgx_event** out) {
+    MGX_REQUIRE(ctx && out, MGX_ERR_INVALID, "NULL argument");
+    mgx_event* e = new mgx_event();
+    hipError_t r = hipEventCreate(&e->ev);
+    if (r != hipSuccess) {
+        delete e;
+        return mgx::fail(MGX_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(r));
+    }
+    *out = e;
+    return MGX_OK;
+}
+
+int mgx_event_destroy(mgx_ctx* ctx, mgx_event* ev) {
+    (void)ctx;
+    if (!ev) return MGX_OK;
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return MGX_OK;
+}
+
+int mgx_event_record(mgx_ctx* ctx, mgx_event* ev) {
+    MGX_REQUIRE(ctx && ev, MGX_ERR_INVALID, "NULL argument");
+    MGX_HIP(hipEventRecord(ev->ev, ctx->compute));
+    return MGX_OK;
+}
+
+int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float* ms) {
+    MGX_REQUIRE(ctx && start && stop && ms, MGX_ERR_INVALID, "NULL argument");
+    MGX_HIP(hipEventSynchronize(stop->ev));
+    MGX_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return MGX_OK;
+}
+
+}  // extern "C"

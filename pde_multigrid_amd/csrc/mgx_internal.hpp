@@ -1,0 +1,64 @@
+// mgx_internal.hpp -- shared by the HIP translation units behind include/mgx.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "mgx.h"
+
+struct mgx_ctx {
+    int device = 0;
+    hipStream_t compute = nullptr;  // every kernel
+    hipStream_t comm = nullptr;     // RCCL halo exchange / collectives
+    hipEvent_t ev_compute = nullptr;  // compute -> comm ordering
+    hipEvent_t ev_comm = nullptr;     // comm -> compute ordering
+    void* scratch = nullptr;  // small device workspace (reductions, tables)
+    size_t scratch_bytes = 0;
+    void* rccl_comm = nullptr;  // ncclComm_t
+    int rank = 0, nranks = 1;
+    int num_cus = 256;
+};
+
+struct mgx_event {
+    hipEvent_t ev = nullptr;
+};
+
+namespace mgx {
+
+void set_error(const char* fmt, ...);
+
+inline int fail(int status, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    set_error("%s", buf);
+    return status;
+}
+
+// workspace of at least `bytes` (grown on demand; contents undefined)
+int workspace(mgx_ctx* ctx, size_t bytes, void** out);
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+inline bool valid_size(int n) { return n >= 3 && ((n - 1) % 2 == 0); }
+
+}  // namespace mgx
+
+#define MGX_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return mgx::fail(MGX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define MGX_REQUIRE(cond, status, ...) \
+    do {                               \
+        if (!(cond)) return mgx::fail(status, __VA_ARGS__); \
+    } while (0)
+
+#define MGX_LAUNCH_CHECK() MGX_HIP(hipGetLastError())

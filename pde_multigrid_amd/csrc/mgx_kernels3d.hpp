@@ -1,0 +1,73 @@
+// mgx_kernels3d.hpp -- per-point expressions of the 3D operators (device inline), shared by
+// the natural-layout kernels (mgx_kernels3d.hip) and the red-black planar ones (mgx_rb3d.hip).
+//
+// These are the ONLY places where the arithmetic of the reference is restated on the device;
+// each keeps the reference's association order so that results are bit-identical
+// (-ffp-contract=off; `/` is IEEE-correct for float and double on gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mgx.h"
+
+namespace mgx {
+
+// MultiGrid3D::Relax per-point update.                      N3/MultiGrid3D.cpp:532 (=:561)
+//   v = (O*(hy2*hz2)+E*(hy2*hz2) + N*(hx2*hz2)+S*(hx2*hz2) + D*(hx2*hy2)+U*(hx2*hy2)
+//        - f*hx2*hy2*hz2) / (2*(hy2*hz2 + hx2*hz2 + hx2*hy2))
+// O/E = x-1/x+1, N/S = y-1/y+1, D/U = z-1/z+1 (:518-529).
+template <class real>
+__device__ __forceinline__ real relax3d_point(real O, real E, real N, real S, real D, real U, real f, real hx2,
+                                              real hy2, real hz2) {
+    return (O * (hy2 * hz2) + E * (hy2 * hz2) + N * (hx2 * hz2) + S * (hx2 * hz2) + D * (hx2 * hy2) + U * (hx2 * hy2) -
+            f * hx2 * hy2 * hz2) /
+           (2 * (hy2 * hz2 + hx2 * hz2 + hx2 * hy2));
+}
+
+// MultiGrid3D::CalculateResidual interior expression.       N3/MultiGrid3D.cpp:723
+// MODE 0 = REF_COMPAT (the reference's -S / -U), MODE 1 = CORRECT (+S / +U).
+template <class real, int MODE>
+__device__ __forceinline__ real residual3d_point(real O, real E, real N, real S, real D, real U, real c, real f,
+                                                 real hx2, real hy2, real hz2) {
+    if (MODE == 0) return f - ((O - 2 * c + E) / hx2) - ((N - 2 * c - S) / hy2) - ((D - 2 * c - U) / hz2);
+    return f - ((O - 2 * c + E) / hx2) - ((N - 2 * c + S) / hy2) - ((D - 2 * c + U) / hz2);
+}
+
+// MultiGrid3D::Restrict interior formula.                   N3/MultiGrid3D.cpp:122-180
+// get(dx,dy,dz) returns the fine value at offset (dx,dy,dz) from the fine point 2*(cx,cy,cz).
+// Reference names: suffix _C/_N/_S = y, y-1, y+1; prefix N/S = z+1/z-1, E/O = x+1/x-1.
+template <class real, class Get>
+__device__ __forceinline__ real restrict3d_point(Get get) {
+    const real C_C = get(0, 0, 0), N_C = get(0, 0, 1), S_C = get(0, 0, -1), E_C = get(1, 0, 0), O_C = get(-1, 0, 0);
+    const real NE_C = get(1, 0, 1), NO_C = get(-1, 0, 1), SE_C = get(1, 0, -1), SO_C = get(-1, 0, -1);
+    const real C_N = get(0, -1, 0), N_N = get(0, -1, 1), S_N = get(0, -1, -1), E_N = get(1, -1, 0), O_N = get(-1, -1, 0);
+    const real NE_N = get(1, -1, 1), NO_N = get(-1, -1, 1), SE_N = get(1, -1, -1), SO_N = get(-1, -1, -1);
+    const real C_S = get(0, 1, 0), N_S = get(0, 1, 1), S_S = get(0, 1, -1), E_S = get(1, 1, 0), O_S = get(-1, 1, 0);
+    const real NE_S = get(1, 1, 1), NO_S = get(-1, 1, 1), SE_S = get(1, 1, -1), SO_S = get(-1, 1, -1);
+    return (1 / 8.0f) * (C_C) + (1 / 16.0f) * ((N_C + E_C + S_C + O_C) + (C_N + C_S)) +
+           (1 / 32.0f) * ((NE_C + SE_C + SO_C + NO_C) + (N_N + E_N + S_N + O_N) + (N_S + E_S + S_S + O_S)) +
+           (1 / 64.0f) * ((NE_N + SE_N + SO_N + NO_N) + (NE_S + SE_S + SO_S + NO_S));
+}
+
+// MultiGrid3D::Interpolate value of a fine interior point by parity class.
+// ox/oy/oz = fine index odd?; get(dx,dy,dz) = coarse value at (x/2+dx, y/2+dy, z/2+dz).
+//                                                           N3/MultiGrid3D.cpp:216-329
+template <class real, class Get>
+__device__ __forceinline__ real interpolate3d_point(int ox, int oy, int oz, Get get) {
+    if (!oz) {
+        if (!oy) {
+            if (!ox) return get(0, 0, 0);                                             // PPP :216
+            return (1 / 2.0f) * (get(0, 0, 0) + get(1, 0, 0));                        // PDP :222-229
+        }
+        if (!ox) return (1 / 2.0f) * (get(0, 0, 0) + get(0, 1, 0));                   // DPP :233-240
+        return (1 / 4.0f) * (get(0, 0, 0) + get(1, 0, 0) + get(0, 1, 0) + get(1, 1, 0));  // DDP :244-255
+    }
+    if (!oy) {
+        if (!ox) return (1 / 2.0f) * (get(0, 0, 0) + get(0, 0, 1));                   // PPD :261-268
+        return (1 / 4.0f) * (get(0, 0, 1) + get(1, 0, 1) + get(0, 0, 0) + get(1, 0, 0));  // PDD :272-283
+    }
+    if (!ox) return (1 / 4.0f) * (get(0, 0, 0) + get(0, 0, 1) + get(0, 1, 0) + get(0, 1, 1));  // DPD :287-298
+    return (1 / 8.0f) * (get(0, 0, 0) + get(0, 0, 1) + get(1, 0, 1) + get(1, 0, 0) + get(0, 1, 0) + get(0, 1, 1) +
+                         get(1, 1, 1) + get(1, 1, 0));                                // DDD :302-329
+}
+
+}  // namespace mgx

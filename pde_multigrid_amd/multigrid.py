@@ -1,0 +1,523 @@
+"""ctypes views of the C host layer (include/mg_multigrid.h) and of the raw operator C-ABI
+(include/mgx.h).  numpy arrays are indexed [z, y, x] (x fastest in memory): the reference's
+idx = x + y*sx + z*sx*sy.  Sizes are given as (sx, sy, sz) like the reference's sizeXYZ."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import REF_COMPAT, check, lib
+
+
+def _ct(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "f32", C.c_float
+    if dtype == np.float64:
+        return "f64", C.c_double
+    raise TypeError("dtype must be float32 or float64, got %s" % dtype)
+
+
+def _ip(a):
+    return (C.c_int * len(a))(*[int(x) for x in a])
+
+
+def _rp(a, ct):
+    return (ct * len(a))(*[float(x) for x in a])
+
+
+def _shape(n):
+    return tuple(int(k) for k in reversed(tuple(n)))
+
+
+def _count(n):
+    c = 1
+    for k in n:
+        c *= int(k)
+    return c
+
+
+def num_grids(min_size):
+    return lib.mg_num_grids(int(min_size))
+
+
+def coarse_size(n):
+    return tuple(lib.mg_coarse_size(int(k)) for k in n)
+
+
+def grid_spacing(n, rng, dtype):
+    """h = range/(real)(size-1) evaluated in `dtype` like Grid3D's constructor (N3/Grid3D.cpp:31-45)."""
+    t = np.dtype(dtype).type
+    return [t(t(rng[2 * d + 1]) - t(rng[2 * d])) / t(int(n[d]) - 1) for d in range(len(n))]
+
+
+class Context:
+    """One HIP device context (compute + comm stream)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib.mgx_ctx_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib.mgx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib.mgx_ctx_sync(self._h))
+
+    # -- raw device memory --------------------------------------------------
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(lib.mgx_malloc(self._h, C.c_size_t(int(nbytes)), C.byref(p)))
+        return p
+
+    def free(self, p):
+        check(lib.mgx_free(self._h, p))
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        check(lib.mgx_memcpy_h2d(self._h, p, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
+        return p
+
+    def to_host(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        check(lib.mgx_memcpy_d2h(self._h, out.ctypes.data_as(C.c_void_p), p, C.c_size_t(out.nbytes)))
+        return out
+
+    # -- events on the compute stream -----------------------------------------
+    def event(self):
+        e = C.c_void_p()
+        check(lib.mgx_event_create(self._h, C.byref(e)))
+        return e
+
+    def record(self, e):
+        check(lib.mgx_event_record(self._h, e))
+
+    def elapsed_ms(self, e0, e1):
+        ms = C.c_float()
+        check(lib.mgx_event_elapsed_ms(self._h, e0, e1, C.byref(ms)))
+        return float(ms.value)
+
+    # -- RCCL -------------------------------------------------------------------
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        check(lib.mgx_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        check(lib.mgx_comm_init(self._h, buf, int(rank), int(nranks)))
+
+
+# --------------------------------------------------------------------------- raw operators
+class _Ops:
+    """Per-operator entry points of mgx.h on numpy arrays: upload, launch, download.  Used by the
+    parity tests; the cycle code in C keeps everything resident instead."""
+
+    def __init__(self, dim):
+        self.dim = dim
+        self.p = "mgx%dd_" % dim
+
+    def _fn(self, name, dtype):
+        s, ct = _ct(dtype)
+        return getattr(lib, self.p + name + "_" + s), ct
+
+    def _run(self, ctx, arrays, call, out_index, out_shape, dtype):
+        ptrs = [ctx.to_device(np.ascontiguousarray(a, dtype=dtype)) if a is not None else None for a in arrays]
+        try:
+            check(call(*ptrs))
+            return ctx.to_host(ptrs[out_index], out_shape, dtype)
+        finally:
+            for p in ptrs:
+                if p is not None:
+                    ctx.free(p)
+
+    def restrict(self, ctx, fine, n, cn=None, dtype=None):
+        dtype = dtype or fine.dtype
+        fn, _ = self._fn("restrict", dtype)
+        cn = cn if cn is not None else coarse_size(n)
+        coarse = np.zeros(_shape(cn), dtype)
+        return self._run(ctx, [fine, coarse], lambda f, c: fn(ctx._h, f, _ip(n), c, _ip(cn)), 1, _shape(cn), dtype)
+
+    def interpolate(self, ctx, fine, n, coarse, cn=None, dtype=None):
+        dtype = dtype or fine.dtype
+        fn, _ = self._fn("interpolate", dtype)
+        cn = cn if cn is not None else coarse_size(n)
+        return self._run(ctx, [fine, coarse], lambda f, c: fn(ctx._h, f, _ip(n), c, _ip(cn)), 0, _shape(n), dtype)
+
+    def apply_correction(self, ctx, fine, n, err, en=None, dtype=None):
+        dtype = dtype or fine.dtype
+        fn, _ = self._fn("apply_correction", dtype)
+        en = en if en is not None else n
+        return self._run(ctx, [fine, err], lambda f, e: fn(ctx._h, f, _ip(n), e, _ip(en)), 0, _shape(n), dtype)
+
+    def set(self, ctx, grid, n, value, modify_boundaries, dtype=None):
+        dtype = dtype or grid.dtype
+        fn, ct = self._fn("set", dtype)
+        return self._run(ctx, [grid], lambda g: fn(ctx._h, g, _ip(n), ct(value), C.c_int(int(modify_boundaries))), 0,
+                         _shape(n), dtype)
+
+
+class _Ops3D(_Ops):
+    def __init__(self):
+        super().__init__(3)
+
+    def relax(self, ctx, v, f, n, rng, ncycles, dtype=None):
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("relax", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        return self._run(ctx, [v, f], lambda a, b: fn(ctx._h, a, b, _ip(n), h, C.c_int(ncycles)), 0, _shape(n), dtype)
+
+    def residual(self, ctx, v, f, n, rng, mode=REF_COMPAT, dtype=None):
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("residual", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        r = np.zeros(_shape(n), dtype)
+        return self._run(ctx, [v, f, r], lambda a, b, c: fn(ctx._h, a, b, c, _ip(n), h, C.c_int(mode)), 2, _shape(n), dtype)
+
+    def residual_restrict(self, ctx, v, f, n, rng, mode=REF_COMPAT, dtype=None):
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("residual_restrict", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        cn = coarse_size(n)
+        coarse = np.zeros(_shape(cn), dtype)
+        return self._run(ctx, [v, f, coarse], lambda a, b, c: fn(ctx._h, a, b, _ip(n), h, C.c_int(mode), c, _ip(cn)), 2,
+                         _shape(cn), dtype)
+
+    def interpolate_correct(self, ctx, v, n, coarse, dtype=None):
+        dtype = dtype or v.dtype
+        fn, _ = self._fn("interpolate_correct", dtype)
+        cn = coarse_size(n)
+        return self._run(ctx, [v, coarse], lambda a, c: fn(ctx._h, a, _ip(n), c, _ip(cn)), 0, _shape(n), dtype)
+
+    def norm2(self, ctx, x):
+        s, _ = _ct(x.dtype)
+        out = C.c_double()
+        p = ctx.to_device(x)
+        try:
+            check(getattr(lib, "mgx_norm2_" + s)(ctx._h, p, C.c_size_t(x.size), C.byref(out)))
+        finally:
+            ctx.free(p)
+        return float(out.value)
+
+
+class _Ops2D(_Ops):
+    def __init__(self):
+        super().__init__(2)
+
+    def _geom(self, n, rng, A, dtype, ct):
+        t = np.dtype(dtype).type
+        return (_rp(grid_spacing(n, rng, dtype), ct), _rp([t(rng[0]), t(rng[2])], ct), _rp(A, ct))
+
+    def relax(self, ctx, v, f, n, rng, A, alfa, ncycles, dtype=None):
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("relax", dtype)
+        h, a, AA = self._geom(n, rng, A, dtype, ct)
+        return self._run(ctx, [v, f], lambda x, y: fn(ctx._h, x, y, _ip(n), h, a, AA, C.c_int(alfa), C.c_int(ncycles)), 0,
+                         _shape(n), dtype)
+
+    def residual(self, ctx, v, f, n, rng, A, alfa, dtype=None):
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("residual", dtype)
+        h, a, AA = self._geom(n, rng, A, dtype, ct)
+        r = np.zeros(_shape(n), dtype)
+        return self._run(ctx, [v, f, r], lambda x, y, z: fn(ctx._h, x, y, z, _ip(n), h, a, AA, C.c_int(alfa)), 2, _shape(n),
+                         dtype)
+
+
+ops3d = _Ops3D()
+ops2d = _Ops2D()
+
+
+# --------------------------------------------------------------------------- hierarchy views
+def _grid3_struct(ct):
+    class Grid3D(C.Structure):
+        _fields_ = [("h_v", C.c_void_p), ("h_f", C.c_void_p), ("d_v", C.c_void_p), ("d_f", C.c_void_p),
+                    ("d_r", C.c_void_p), ("d_e", C.c_void_p), ("sizeX", C.c_int), ("sizeY", C.c_int), ("sizeZ", C.c_int),
+                    ("sizeXYZ", C.c_int * 3), ("h_x", ct), ("h_y", ct), ("h_z", ct), ("x_a", ct), ("x_b", ct),
+                    ("y_a", ct), ("y_b", ct), ("z_a", ct), ("z_b", ct)]
+
+    class MultiGrid3D(C.Structure):
+        _fields_ = [("grids3D", C.POINTER(C.POINTER(Grid3D))), ("numGrids", C.c_int), ("maxGrids", C.c_int),
+                    ("ctx", C.c_void_p), ("residual_mode", C.c_int), ("fuse", C.c_int)]
+
+    return Grid3D, MultiGrid3D
+
+
+def _grid2_struct(ct):
+    class Grid2D(C.Structure):
+        _fields_ = [("h_v", C.c_void_p), ("h_f", C.c_void_p), ("d_v", C.c_void_p), ("d_f", C.c_void_p),
+                    ("d_r", C.c_void_p), ("d_e", C.c_void_p), ("sizeX", C.c_int), ("sizeY", C.c_int),
+                    ("sizeXY", C.c_int * 2), ("h_x", ct), ("h_y", ct), ("x_a", ct), ("x_b", ct), ("y_a", ct), ("y_b", ct)]
+
+    class MultiGrid2D(C.Structure):
+        _fields_ = [("grids2D", C.POINTER(C.POINTER(Grid2D))), ("numGrids", C.c_int), ("maxGrids", C.c_int),
+                    ("matrixA", ct * 4), ("sizeA", C.c_int), ("alfa", C.c_int), ("ctx", C.c_void_p), ("fuse", C.c_int)]
+
+    return Grid2D, MultiGrid2D
+
+
+def _grid1_struct(ct):
+    class Grid1D(C.Structure):
+        _fields_ = [("h_v", C.POINTER(ct)), ("h_f", C.POINTER(ct)), ("sizeX", C.c_int), ("h_x", ct), ("x_a", ct),
+                    ("x_b", ct)]
+
+    class MultiGrid1D(C.Structure):
+        _fields_ = [("grids1D", C.POINTER(C.POINTER(Grid1D))), ("numGrids", C.c_int), ("maxGrids", C.c_int)]
+
+    return Grid1D, MultiGrid1D
+
+
+class _MGBase:
+    _prefix = None
+
+    def _call(self, name, *args):
+        return check(getattr(lib, "%s_%s_%s" % (self._prefix, self._sfx, name))(self._mg, *args))
+
+    @property
+    def numGrids(self):
+        return self._mg.contents.numGrids
+
+    @numGrids.setter
+    def numGrids(self, k):
+        if not 1 <= int(k) <= self._mg.contents.maxGrids:
+            raise ValueError("numGrids must be in [1, %d]" % self._mg.contents.maxGrids)
+        self._mg.contents.numGrids = int(k)
+
+    @property
+    def maxGrids(self):
+        return self._mg.contents.maxGrids
+
+    def VCycle(self, gridID, v1, v2):
+        self._call("VCycle", C.c_int(gridID), C.c_int(v1), C.c_int(v2))
+
+    def FullMultiGridVCycle(self, gridID, v0, v1, v2):
+        self._call("FullMultiGridVCycle", C.c_int(gridID), C.c_int(v0), C.c_int(v1), C.c_int(v2))
+
+    def close(self):
+        if self._mg:
+            getattr(lib, "%s_%s_destroy" % (self._prefix, self._sfx))(self._mg)
+            self._mg = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiGrid3D(_MGBase):
+    """MultiGrid3D(finestGridSizeXYZ, range) of the reference (N3/MultiGrid3D.h:6-33) on one MI355X."""
+    _prefix = "mgMultiGrid3D"
+
+    def __init__(self, ctx, finestGridSizeXYZ, rng, dtype=np.float64, nlevels=0, residual_mode=REF_COMPAT, fuse=True):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        self._sfx, self._ct = _ct(dtype)
+        self._G, self._M = _grid3_struct(self._ct)
+        self._mg = C.POINTER(self._M)()
+        fn = getattr(lib, "mgMultiGrid3D_%s_create" % self._sfx)
+        check(fn(ctx._h, _ip(finestGridSizeXYZ), _rp(rng, self._ct), C.byref(self._mg)))
+        if nlevels:
+            self.numGrids = nlevels
+        self._mg.contents.residual_mode = int(residual_mode)
+        self._mg.contents.fuse = int(bool(fuse))
+
+    def grid(self, gridID):
+        return self._mg.contents.grids3D[gridID].contents
+
+    def size(self, gridID):
+        return tuple(self.grid(gridID).sizeXYZ)
+
+    def Relax(self, gridID, ncycles):
+        self._call("Relax", self._mg.contents.grids3D[gridID], C.c_int(ncycles))
+
+    def CalculateResidual(self, gridID):
+        r = C.c_void_p()
+        self._call("CalculateResidual", self._mg.contents.grids3D[gridID], C.byref(r))
+        return self.ctx.to_host(r, _shape(self.size(gridID)), self.dtype)
+
+    def ResidualNorm(self, gridID=0):
+        out = C.c_double()
+        self._call("ResidualNorm", C.c_int(gridID), C.byref(out))
+        return float(out.value)
+
+    def InitF(self, gridID):
+        self._call("InitF", C.c_int(gridID))
+
+    def setToValue_v(self, gridID, value, modifyBoundaries):
+        g = self.grid(gridID)
+        self._call("setToValue", C.c_void_p(g.d_v), _ip(g.sizeXYZ), self._ct(value), C.c_int(int(modifyBoundaries)))
+
+    def upload_v(self, gridID, arr):
+        arr = np.ascontiguousarray(arr, self.dtype)
+        assert arr.size == _count(self.size(gridID))
+        self._call("upload_v", C.c_int(gridID), arr.ctypes.data_as(C.c_void_p))
+
+    def upload_f(self, gridID, arr):
+        arr = np.ascontiguousarray(arr, self.dtype)
+        assert arr.size == _count(self.size(gridID))
+        self._call("upload_f", C.c_int(gridID), arr.ctypes.data_as(C.c_void_p))
+
+    def download_v(self, gridID=0):
+        out = np.empty(_shape(self.size(gridID)), self.dtype)
+        self._call("download_v", C.c_int(gridID), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def download_f(self, gridID=0):
+        out = np.empty(_shape(self.size(gridID)), self.dtype)
+        self._call("download_f", C.c_int(gridID), out.ctypes.data_as(C.c_void_p))
+        return out
+
+
+class MultiGrid2D(_MGBase):
+    """MultiGrid2D(finestGridSizeXY, range, A, A_size, alfa) (N2/MultiGrid2D.h:6-37) on one MI355X."""
+    _prefix = "mgMultiGrid2D"
+
+    def __init__(self, ctx, finestGridSizeXY, rng, A, alfa, dtype=np.float64, nlevels=0):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        self._sfx, self._ct = _ct(dtype)
+        self._G, self._M = _grid2_struct(self._ct)
+        self._mg = C.POINTER(self._M)()
+        fn = getattr(lib, "mgMultiGrid2D_%s_create" % self._sfx)
+        check(fn(ctx._h, _ip(finestGridSizeXY), _rp(rng, self._ct), _rp(A, self._ct), C.c_int(2), C.c_int(alfa),
+                 C.byref(self._mg)))
+        if nlevels:
+            self.numGrids = nlevels
+
+    def grid(self, gridID):
+        return self._mg.contents.grids2D[gridID].contents
+
+    def size(self, gridID):
+        return tuple(self.grid(gridID).sizeXY)
+
+    def Relax(self, gridID, ncycles):
+        self._call("Relax", self._mg.contents.grids2D[gridID], C.c_int(ncycles))
+
+    def upload_v(self, gridID, arr):
+        arr = np.ascontiguousarray(arr, self.dtype)
+        assert arr.size == _count(self.size(gridID))
+        self._call("upload_v", C.c_int(gridID), arr.ctypes.data_as(C.c_void_p))
+
+    def upload_f(self, gridID, arr):
+        arr = np.ascontiguousarray(arr, self.dtype)
+        assert arr.size == _count(self.size(gridID))
+        self._call("upload_f", C.c_int(gridID), arr.ctypes.data_as(C.c_void_p))
+
+    def download_v(self, gridID=0):
+        out = np.empty(_shape(self.size(gridID)), self.dtype)
+        self._call("download_v", C.c_int(gridID), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def download_f(self, gridID=0):
+        out = np.empty(_shape(self.size(gridID)), self.dtype)
+        self._call("download_f", C.c_int(gridID), out.ctypes.data_as(C.c_void_p))
+        return out
+
+
+class MultiGrid1D(_MGBase):
+    """MultiGrid1D(finestGridSize, range) (N1/MultiGrid1D.h:6-31): host-only C (BASELINE configs[0])."""
+    _prefix = "mgMultiGrid1D"
+
+    def __init__(self, finestGridSize, rng, dtype=np.float32, nlevels=0):
+        self.dtype = np.dtype(dtype)
+        self._sfx, self._ct = _ct(dtype)
+        self._G, self._M = _grid1_struct(self._ct)
+        self._mg = C.POINTER(self._M)()
+        fn = getattr(lib, "mgMultiGrid1D_%s_create" % self._sfx)
+        check(fn(C.c_int(finestGridSize), _rp(rng, self._ct), C.byref(self._mg)))
+        if nlevels:
+            self.numGrids = nlevels
+
+    def grid(self, gridID):
+        return self._mg.contents.grids1D[gridID].contents
+
+    def _view(self, ptr, n):
+        return np.ctypeslib.as_array(ptr, shape=(n,))
+
+    def v(self, gridID=0):
+        g = self.grid(gridID)
+        return self._view(g.h_v, g.sizeX)
+
+    def f(self, gridID=0):
+        g = self.grid(gridID)
+        return self._view(g.h_f, g.sizeX)
+
+    def Relax(self, gridID, ncycles):
+        self._call("Relax", self._mg.contents.grids1D[gridID], C.c_int(ncycles))
+
+    def CalculateResidual(self, gridID):
+        g = self.grid(gridID)
+        r = np.empty(g.sizeX, self.dtype)
+        self._call("CalculateResidual", self._mg.contents.grids1D[gridID], r.ctypes.data_as(C.c_void_p))
+        return r
+
+    def Restrict(self, fine):
+        fine = np.ascontiguousarray(fine, self.dtype)
+        coarse = np.empty((fine.size - 1) // 2 + 1, self.dtype)
+        self._call("Restrict", fine.ctypes.data_as(C.c_void_p), C.c_int(fine.size), coarse.ctypes.data_as(C.c_void_p),
+                   C.c_int(coarse.size))
+        return coarse
+
+    def Interpolate(self, fine, coarse):
+        fine = np.ascontiguousarray(fine, self.dtype).copy()
+        coarse = np.ascontiguousarray(coarse, self.dtype)
+        self._call("Interpolate", fine.ctypes.data_as(C.c_void_p), C.c_int(fine.size), coarse.ctypes.data_as(C.c_void_p),
+                   C.c_int(coarse.size))
+        return fine
+
+    def ApplyCorrection(self, fine, err):
+        fine = np.ascontiguousarray(fine, self.dtype).copy()
+        err = np.ascontiguousarray(err, self.dtype)
+        self._call("ApplyCorrection", fine.ctypes.data_as(C.c_void_p), C.c_int(fine.size), err.ctypes.data_as(C.c_void_p),
+                   C.c_int(err.size))
+        return fine
+
+    def setToValue(self, grid, value, modifyBoundaries):
+        grid = np.ascontiguousarray(grid, self.dtype).copy()
+        self._call("setToValue", grid.ctypes.data_as(C.c_void_p), C.c_int(grid.size), self._ct(value),
+                   C.c_int(int(modifyBoundaries)))
+        return grid
+
+
+# --------------------------------------------------------------------------- solve(grid, rhs, nlevels)
+def solve3d(ctx, grid, rhs, rng, nlevels=0, fmg=False, v0=1, v1=2, v2=2, ncycles=1, residual_mode=REF_COMPAT):
+    grid = np.ascontiguousarray(grid).copy()
+    s, ct = _ct(grid.dtype)
+    rhs = np.ascontiguousarray(rhs, grid.dtype)
+    n = tuple(reversed(grid.shape))
+    check(getattr(lib, "mg3d_solve_" + s)(ctx._h, grid.ctypes.data_as(C.c_void_p), rhs.ctypes.data_as(C.c_void_p), _ip(n),
+                                          _rp(rng, ct), C.c_int(nlevels), C.c_int(int(fmg)), C.c_int(v0), C.c_int(v1),
+                                          C.c_int(v2), C.c_int(ncycles), C.c_int(residual_mode)))
+    return grid
+
+
+def solve2d(ctx, grid, rhs, rng, A, alfa, nlevels=0, fmg=False, v0=1, v1=2, v2=2, ncycles=1):
+    grid = np.ascontiguousarray(grid).copy()
+    s, ct = _ct(grid.dtype)
+    rhs = np.ascontiguousarray(rhs, grid.dtype)
+    n = tuple(reversed(grid.shape))
+    check(getattr(lib, "mg2d_solve_" + s)(ctx._h, grid.ctypes.data_as(C.c_void_p), rhs.ctypes.data_as(C.c_void_p), _ip(n),
+                                          _rp(rng, ct), _rp(A, ct), C.c_int(alfa), C.c_int(nlevels), C.c_int(int(fmg)),
+                                          C.c_int(v0), C.c_int(v1), C.c_int(v2), C.c_int(ncycles)))
+    return grid
+
+
+def solve1d(grid, rhs, rng, nlevels=0, fmg=False, v0=1, v1=2, v2=2, ncycles=1):
+    grid = np.ascontiguousarray(grid).copy()
+    s, ct = _ct(grid.dtype)
+    rhs = np.ascontiguousarray(rhs, grid.dtype)
+    check(getattr(lib, "mg1d_solve_" + s)(grid.ctypes.data_as(C.c_void_p), rhs.ctypes.data_as(C.c_void_p),
+                                          C.c_int(grid.size), _rp(rng, ct), C.c_int(nlevels), C.c_int(int(fmg)),
+                                          C.c_int(v0), C.c_int(v1), C.c_int(v2), C.c_int(ncycles)))
+    return grid
