@@ -141,7 +141,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "relax3d_colour_kernel<%s> (finest level, one colour per launch)" % ("double" if wbytes == 8 else "float"),
+            "kernel": "relax3d_xs_kernel<%s> (finest level, x-split layout, one colour per launch)" % ("double" if wbytes == 8 else "float"),
             "achieved": round(achieved / 1e9, 1),
             "peak": HBM_PEAK_BPS / 1e9,
             "unit": "GB/s",

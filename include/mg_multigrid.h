@@ -15,8 +15,11 @@
  * after construction), same cycle control flow (VCycle N3/MultiGrid3D.cpp:623-647,
  * FullMultiGridVCycle :569-585).  Differences, all at the boundary:
  *   - every function returns an int status (mgx_status) instead of asserting/aborting;
- *   - d_v / d_f are device arrays (reference layout: dense, x fastest); h_v / h_f are host
- *     mirrors filled by *_download_* and pushed by *_upload_*;
+ *   - d_v / d_f are device arrays; h_v / h_f are host mirrors (always the reference layout:
+ *     dense, x fastest) filled by *_download_* and pushed by *_upload_*.  The 3D hierarchy keeps
+ *     its device arrays in the x-split layout of mgx.h by default (`layout` = 1; rows
+ *     de-interleaved by x parity so that each colour pass streams contiguous half-rows); raw
+ *     device pointers handed to Restrict/Interpolate/... must use the hierarchy's layout;
  *   - residual / error scratch is owned by the level and preallocated (the reference mallocs
  *     both inside every VCycle call and never frees them, N3/MultiGrid3D.cpp:629,638);
  *   - `residual_mode` selects REF_COMPAT (default; reproduces the 3D residual sign quirk,
@@ -55,9 +58,12 @@ extern "C" {
         mgx_ctx* ctx;                                                                                    \
         int residual_mode; /* mgx_residual_mode */                                                       \
         int fuse;                                                                                        \
+        int layout; /* device layout of d_v/d_f/d_r/d_e: 0 = reference layout, 1 = x-split (mgx.h) */    \
     } mgMultiGrid3D_##R;                                                                                 \
     int mgMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6],     \
                                    mgMultiGrid3D_##R** out);                                             \
+    int mgMultiGrid3D_##R##_create_layout(mgx_ctx* ctx, const int finestGridSizeXYZ[3],                  \
+                                          const real range[6], int layout, mgMultiGrid3D_##R** out);     \
     void mgMultiGrid3D_##R##_destroy(mgMultiGrid3D_##R* mg);                                             \
     int mgMultiGrid3D_##R##_InitV(mgMultiGrid3D_##R* mg, int gridID);                                    \
     int mgMultiGrid3D_##R##_InitF(mgMultiGrid3D_##R* mg, int gridID);                                    \
@@ -79,6 +85,7 @@ extern "C" {
     int mgMultiGrid3D_##R##_upload_f(mgMultiGrid3D_##R* mg, int gridID, const real* host);               \
     int mgMultiGrid3D_##R##_download_v(mgMultiGrid3D_##R* mg, int gridID, real* host);                   \
     int mgMultiGrid3D_##R##_download_f(mgMultiGrid3D_##R* mg, int gridID, real* host);                   \
+    int mgMultiGrid3D_##R##_download_residual(mgMultiGrid3D_##R* mg, int gridID, real* host);            \
     int mgMultiGrid3D_##R##_ResidualNorm(mgMultiGrid3D_##R* mg, int gridID, double* l2);                 \
     /* solve(grid, rhs, nlevels): host arrays in the reference layout; grid = initial guess incl.     */ \
     /* boundary values on input, solution on output; nlevels = 0 -> reference rule; ncycles V(v1,v2)  */ \

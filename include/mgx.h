@@ -79,6 +79,9 @@ int mgx_ctx_create(int device, mgx_ctx** out);
 int mgx_ctx_destroy(mgx_ctx* ctx);
 int mgx_ctx_sync(mgx_ctx* ctx);                 /* waits for the compute and comm streams */
 int mgx_ctx_device(const mgx_ctx* ctx, int* device);
+/* tuning knobs (speed only, never results): "relax3d.ty" in {1,2,4,8} rows per block and
+ * "relax3d.zchunk" planes per block (0 = automatic) of the x-split smoother kernel */
+int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value);
 /* raw hipStream_t of the compute stream (for callers that bring their own HIP code) */
 int mgx_ctx_stream(const mgx_ctx* ctx, void** hip_stream);
 
@@ -110,6 +113,12 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
  * mgx3d_interpolate_correct: v += Interpolate(coarse_v) on the interior.
  * mgx3d_init_f: f[x,y,z] = (real)(c * tx[x] * ty[y] * tz[z]) evaluated in double, left to
  *   right (Grid3D::InitF with host-computed sin tables; tables are host pointers).
+ * mgx3dxs_*: the same operators on the device-internal "x-split" layout
+ *   idx = (x>>1) + (x&1)*((sx+1)/2) + y*sx + z*sx*sy
+ *   (every x-row stored as its even-x half followed by its odd-x half; rows and planes in the
+ *   reference order).  In row (y,z) the points of one colour are one contiguous half-row, so a
+ *   red+black sweep moves the algorithmic minimum of 3 reals per point through HBM.  Results are
+ *   bit-identical to the natural-layout operators; mgx3dxs_pack / _unpack convert (out of place).
  * mgx_norm2: sum of squares of `count` reals in double (wave-wide shuffle reduction +
  *   one atomic per block); host result, blocking.  An addition: the reference has no norm.
  */
@@ -131,6 +140,26 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                                         const int cn[3]);                                               \
     int mgx3d_init_f_##SFX(mgx_ctx* ctx, real* f, const int n[3], double c, const double* host_tx,      \
                            const double* host_ty, const double* host_tz);                               \
+    /* x-split twins: same operators on arrays whose x-rows are de-interleaved (see below) */           \
+    int mgx3dxs_pack_##SFX(mgx_ctx* ctx, const real* natural, real* xsplit, const int n[3]);            \
+    int mgx3dxs_unpack_##SFX(mgx_ctx* ctx, const real* xsplit, real* natural, const int n[3]);          \
+    int mgx3dxs_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3],      \
+                            int ncycles);                                                               \
+    int mgx3dxs_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3],     \
+                               const real h[3], int mode);                                              \
+    int mgx3dxs_restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse,           \
+                               const int cn[3]);                                                        \
+    int mgx3dxs_interpolate_##SFX(mgx_ctx* ctx, real* fine, const int fn[3], const real* coarse,        \
+                                  const int cn[3]);                                                     \
+    int mgx3dxs_apply_correction_##SFX(mgx_ctx* ctx, real* fine, const int fn[3], const real* err,      \
+                                       const int en[3]);                                                \
+    int mgx3dxs_set_##SFX(mgx_ctx* ctx, real* grid, const int n[3], real value, int modify_boundaries); \
+    int mgx3dxs_residual_restrict_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[3],     \
+                                        const real h[3], int mode, real* coarse_f, const int cn[3]);    \
+    int mgx3dxs_interpolate_correct_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,  \
+                                          const int cn[3]);                                             \
+    int mgx3dxs_init_f_##SFX(mgx_ctx* ctx, real* f, const int n[3], double c, const double* host_tx,    \
+                             const double* host_ty, const double* host_tz);                             \
     int mgx2d_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[2], const real h[2],        \
                           const real a[2], const real A[4], int alfa, int ncycles);                     \
     int mgx2d_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[2],       \

@@ -4,10 +4,23 @@
 // association order, in `real`, with true IEEE division and without FMA contraction
 // (this file is compiled with -ffp-contract=off), so results are bit-identical to the
 // serial CPU loops: red-black Gauss-Seidel is order-independent within a colour
-// (SURVEY.md section 0, fact 7).  Layout: dense, x fastest, idx = x + y*sx + z*sx*sy.
+// (SURVEY.md section 0, fact 7).
+//
+// Two array layouts (mgx_kernels3d.hpp):
+//   Natural  idx = x + y*sx + z*sx*sy          the reference layout, used at the ABI boundary
+//   XSplit   idx = (x>>1) + (x&1)*H + y*sx + z*sx*sy, H = (sx+1)/2
+//            every x-row is de-interleaved into its even-x half followed by its odd-x half.
+//            In row (y,z) the points of colour c are exactly the half with x parity
+//            (c+y+z)&1, so one colour pass of the smoother reads and writes contiguous
+//            half-rows: a red+black sweep moves 3 reals per point through HBM (read the
+//            other colour, read f of this colour, write this colour) instead of the 6 the
+//            interleaved layout needs.  Rows and planes keep their natural order, so z-slabs
+//            and ghost planes stay contiguous.
 //
 // Kernels (reference function each one replaces):
-//   relax3d_colour_kernel     one colour of MultiGrid3D::Relax        N3/MultiGrid3D.cpp:489-567
+//   relax3d_colour_kernel     one colour of MultiGrid3D::Relax, Natural   N3/MultiGrid3D.cpp:489-567
+//   relax3d_xs_kernel         one colour of MultiGrid3D::Relax, XSplit, z-marching with
+//                             register reuse of the z-1 / z / z+1 column values
 //   residual3d_kernel         MultiGrid3D::CalculateResidual          N3/MultiGrid3D.cpp:678-730
 //   restrict3d_kernel         MultiGrid3D::Restrict                   N3/MultiGrid3D.cpp:50-184
 //   interpolate3d_kernel      MultiGrid3D::Interpolate (+ApplyCorrection when ADD)
@@ -16,12 +29,13 @@
 //   set3d_kernel              MultiGrid3D::setToValue                 N3/MultiGrid3D.cpp:587-621
 //   init_f3d_kernel           Grid3D::InitF                           N3/Grid3D.cpp:78-96
 //   residual_restrict3d_kernel  CalculateResidual + Restrict fused through LDS
+//   relayout3d_kernel         Natural <-> XSplit (upload / download of the hierarchy)
 #include "mgx_internal.hpp"
 #include "mgx_kernels3d.hpp"
 
 namespace mgx {
 
-// ------------------------------------------------------------------ relax, one colour
+// ------------------------------------------------------------------ relax, one colour, Natural
 // One thread per point of the colour.  x = 2*ix + p with p = (colour + y + z) & 1 so that
 // (x + y + z) % 2 == colour  (red = 0: N3/MultiGrid3D.cpp:515, black = 1: :544).
 template <class real>
@@ -41,8 +55,56 @@ __global__ void __launch_bounds__(256) relax3d_colour_kernel(real* __restrict__ 
     v[i] = relax3d_point<real>(O, E, N, S, D, U, f[i], hx2, hy2, hz2);
 }
 
+// ------------------------------------------------------------------ relax, one colour, XSplit
+// Thread (j, y) owns the x-pair {2j, 2j+1} of row y and marches through the planes
+// [z0, z1) of its z-chunk.  In plane z the point of `colour` in that pair is x = 2j + q,
+// q = (colour + y + z) & 1; it lives in half q of the row at index j.  Its six neighbours are
+// of the other colour (never written in this pass, so in-place is race-free):
+//   W, E : half 1-q of the same row, indices j-1+q and j+q (one of them is index j = "own")
+//   N, S : half q, index j, rows y-1 / y+1
+//   D, U : half q, index j, planes z-1 / z+1
+// and (half q, j, plane z+1) is exactly the "own" same-row value of step z+1, while
+// (half q, j, plane z-1) was the "own" value of step z-1: the column is carried in three
+// registers, so each step issues one streaming load of v (U), one of f, one store, and three
+// loads that hit in L1/L2 (the side neighbour and N/S were streamed in by adjacent threads one
+// step earlier).  vin and vout alias the same array; the entries read and the entries written
+// are disjoint by colour, which is what makes the __restrict__ qualification legitimate.
+template <class real, int TY>
+__global__ void __launch_bounds__(64 * TY)
+    relax3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
+                      int sz, real hx2, real hy2, real hz2, int colour, int zchunk) {
+    const int H = (sx + 1) >> 1;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int y = 1 + blockIdx.y * TY + threadIdx.y;
+    if (y >= sy - 1 || j >= H - 1) return;  // x = 2j+q <= sx-2 needs j <= H-2
+    const int z0 = 1 + blockIdx.z * zchunk;
+    const int z1 = min(z0 + zchunk, sz - 1);
+    if (z0 >= z1) return;
+    const size_t sxy = (size_t)sx * sy;
+    size_t row = (size_t)y * sx + (size_t)z0 * sxy;  // base of row (y, z)
+    int q = (colour + y + z0) & 1;
+    real c_prev = vin[row - sxy + q * H + j];       // (half q(z0),   j, plane z0-1)
+    real c_cur = vin[row + (1 - q) * H + j];        // (half 1-q(z0), j, plane z0)
+#pragma unroll 2
+    for (int z = z0; z < z1; z++) {
+        const int hq = q * H, ho = (1 - q) * H;
+        const real c_next = vin[row + sxy + hq + j];  // U, and next step's own value
+        if (q | j) {                                  // x = 2j+q >= 1
+            const real side = q ? vin[row + ho + j + 1] : vin[row + ho + j - 1];
+            const real W = q ? c_cur : side;
+            const real E = q ? side : c_cur;
+            const real N = vin[row - sx + hq + j], S = vin[row + sx + hq + j];
+            vout[row + hq + j] = relax3d_point<real>(W, E, N, S, c_prev, c_next, f[row + hq + j], hx2, hy2, hz2);
+        }
+        c_prev = c_cur;
+        c_cur = c_next;
+        row += sxy;
+        q ^= 1;
+    }
+}
+
 // ------------------------------------------------------------------ residual
-template <class real, int MODE>
+template <class real, class L, int MODE>
 __global__ void __launch_bounds__(256) residual3d_kernel(const real* __restrict__ v, const real* __restrict__ f,
                                                          real* __restrict__ r, int sx, int sy, int sz, real hx2,
                                                          real hy2, real hz2) {
@@ -50,78 +112,84 @@ __global__ void __launch_bounds__(256) residual3d_kernel(const real* __restrict_
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int z = blockIdx.z;
     if (x >= sx || y >= sy) return;
+    const int H = (sx + 1) >> 1;
     const size_t sxy = (size_t)sx * sy;
-    const size_t i = x + (size_t)y * sx + (size_t)z * sxy;
+    const size_t row = (size_t)y * sx + (size_t)z * sxy;
+    const size_t i = row + L::pos(x, H);
     if (x == 0 || x == sx - 1 || y == 0 || y == sy - 1 || z == 0 || z == sz - 1) {
         r[i] = (real)0;  // N3/MultiGrid3D.cpp:704-705
         return;
     }
-    r[i] = residual3d_point<real, MODE>(v[i - 1], v[i + 1], v[i - sx], v[i + sx], v[i - sxy], v[i + sxy], v[i], f[i],
-                                        hx2, hy2, hz2);
+    r[i] = residual3d_point<real, MODE>(v[row + L::pos(x - 1, H)], v[row + L::pos(x + 1, H)], v[i - sx], v[i + sx],
+                                        v[i - sxy], v[i + sxy], v[i], f[i], hx2, hy2, hz2);
 }
 
 // ------------------------------------------------------------------ restrict
-template <class real>
+template <class real, class L>
 __global__ void __launch_bounds__(256) restrict3d_kernel(const real* __restrict__ fine, int fx, int fy,
                                                          real* __restrict__ coarse, int cx, int cy, int cz) {
     const int px = blockIdx.x * blockDim.x + threadIdx.x;
     const int py = blockIdx.y * blockDim.y + threadIdx.y;
     const int pz = blockIdx.z;
     if (px >= cx || py >= cy) return;
+    const int FH = (fx + 1) >> 1, CH = (cx + 1) >> 1;
     const size_t fxy = (size_t)fx * fy;
-    const size_t ci = px + (size_t)py * cx + (size_t)pz * cx * cy;
-    const real* c = fine + (2 * px + (size_t)(2 * py) * fx + (size_t)(2 * pz) * fxy);
+    const size_t ci = L::pos(px, CH) + (size_t)py * cx + (size_t)pz * cx * cy;
+    const real* c = fine + ((size_t)(2 * py) * fx + (size_t)(2 * pz) * fxy);  // row base of the fine centre
+    const int gx = 2 * px;
     if (px == 0 || px == cx - 1 || py == 0 || py == cy - 1 || pz == 0 || pz == cz - 1) {
-        coarse[ci] = c[0];  // injection, N3/MultiGrid3D.cpp:113-119
+        coarse[ci] = c[L::pos(gx, FH)];  // injection, N3/MultiGrid3D.cpp:113-119
         return;
     }
     const ptrdiff_t sy_ = fx, sz_ = (ptrdiff_t)fxy;
-    coarse[ci] = restrict3d_point<real>([&](int dx, int dy, int dz) { return c[dx + dy * sy_ + dz * sz_]; });
+    coarse[ci] = restrict3d_point<real>([&](int dx, int dy, int dz) { return c[L::pos(gx + dx, FH) + dy * sy_ + dz * sz_]; });
 }
 
 // ------------------------------------------------------------------ interpolate (+ correct)
 // ADD = false: fine = I(coarse) on the interior        (Interpolate)
 // ADD = true : fine = fine + I(coarse) on the interior (Interpolate into a scratch error
 //              array followed by ApplyCorrection, N3/MultiGrid3D.cpp:638-642, fused)
-template <class real, bool ADD>
+template <class real, class L, bool ADD>
 __global__ void __launch_bounds__(256) interpolate3d_kernel(real* __restrict__ fine, int fx, int fy, int fz,
                                                             const real* __restrict__ coarse, int cx, int cy) {
     const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int z = 1 + blockIdx.z;
     if (x >= fx - 1 || y >= fy - 1 || z >= fz - 1) return;
+    const int FH = (fx + 1) >> 1, CH = (cx + 1) >> 1;
     const size_t cxy = (size_t)cx * cy;
-    const size_t fi = x + (size_t)y * fx + (size_t)z * fx * fy;
-    const real* c = coarse + ((x >> 1) + (size_t)(y >> 1) * cx + (size_t)(z >> 1) * cxy);
-    const real e = interpolate3d_point<real>(x & 1, y & 1, z & 1,
-                                             [&](int dx, int dy, int dz) { return c[dx + (size_t)dy * cx + (size_t)dz * cxy]; });
+    const size_t fi = L::pos(x, FH) + (size_t)y * fx + (size_t)z * fx * fy;
+    const real* c = coarse + ((size_t)(y >> 1) * cx + (size_t)(z >> 1) * cxy);
+    const int gx = x >> 1;
+    const real e = interpolate3d_point<real>(
+        x & 1, y & 1, z & 1, [&](int dx, int dy, int dz) { return c[L::pos(gx + dx, CH) + (size_t)dy * cx + (size_t)dz * cxy]; });
     if (ADD) fine[fi] = fine[fi] + e;  // N3/MultiGrid3D.cpp:672
     else fine[fi] = e;
 }
 
-template <class real>
+template <class real, class L>
 __global__ void __launch_bounds__(256) correct3d_kernel(real* __restrict__ fine, const real* __restrict__ err, int sx,
                                                         int sy, int sz) {
     const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int z = 1 + blockIdx.z;
     if (x >= sx - 1 || y >= sy - 1 || z >= sz - 1) return;
-    const size_t i = x + (size_t)y * sx + (size_t)z * sx * sy;
+    const size_t i = L::pos(x, (sx + 1) >> 1) + (size_t)y * sx + (size_t)z * sx * sy;
     fine[i] = fine[i] + err[i];
 }
 
-template <class real>
+template <class real, class L>
 __global__ void __launch_bounds__(256) set3d_kernel(real* __restrict__ g, int sx, int sy, int sz, real value, int lo) {
     const int x = lo + blockIdx.x * blockDim.x + threadIdx.x;
     const int y = lo + blockIdx.y * blockDim.y + threadIdx.y;
     const int z = lo + blockIdx.z;
     if (x >= sx - lo || y >= sy - lo || z >= sz - lo) return;
-    g[x + (size_t)y * sx + (size_t)z * sx * sy] = value;
+    g[L::pos(x, (sx + 1) >> 1) + (size_t)y * sx + (size_t)z * sx * sy] = value;
 }
 
 // f = (real)(((c * tx[x]) * ty[y]) * tz[z]) in double: Grid3D::InitF's left-to-right product
 // -3*PI*PI*sin(PI*x)*sin(PI*y)*sin(PI*z) with the three sines tabulated on the host.
-template <class real>
+template <class real, class L>
 __global__ void __launch_bounds__(256) init_f3d_kernel(real* __restrict__ f, int sx, int sy, int sz, double c,
                                                        const double* __restrict__ tx, const double* __restrict__ ty,
                                                        const double* __restrict__ tz) {
@@ -129,7 +197,19 @@ __global__ void __launch_bounds__(256) init_f3d_kernel(real* __restrict__ f, int
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int z = blockIdx.z;
     if (x >= sx || y >= sy) return;
-    f[x + (size_t)y * sx + (size_t)z * sx * sy] = (real)(c * tx[x] * ty[y] * tz[z]);
+    f[L::pos(x, (sx + 1) >> 1) + (size_t)y * sx + (size_t)z * sx * sy] = (real)(c * tx[x] * ty[y] * tz[z]);
+}
+
+// dst(layout LD) = src(layout LS), same sizes
+template <class real, class LS, class LD>
+__global__ void __launch_bounds__(256) relayout3d_kernel(const real* __restrict__ src, real* __restrict__ dst, int sx, int sy) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = blockIdx.z;
+    if (x >= sx || y >= sy) return;
+    const int H = (sx + 1) >> 1;
+    const size_t row = (size_t)y * sx + (size_t)z * sx * sy;
+    dst[row + LD::pos(x, H)] = src[row + LS::pos(x, H)];
 }
 
 // ------------------------------------------------------------------ residual + restrict fused
@@ -137,7 +217,7 @@ __global__ void __launch_bounds__(256) init_f3d_kernel(real* __restrict__ f, int
 // residual on the (2*CTX+1) x (2*CTY+1) x 3 fine points the tile's 27-point stencils touch,
 // plane by plane into LDS (boundary points -> 0 exactly like CalculateResidual), then
 // applies the full-weighting formula.  The fine residual never goes to HBM.
-template <class real, int MODE, int CTX, int CTY>
+template <class real, class L, int MODE, int CTX, int CTY>
 __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __restrict__ v, const real* __restrict__ f,
                                                                   int sx, int sy, int sz, real hx2, real hy2, real hz2,
                                                                   real* __restrict__ coarse, int cx, int cy, int cz) {
@@ -147,6 +227,7 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
     const int px0 = blockIdx.x * CTX, py0 = blockIdx.y * CTY;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     const int nthreads = blockDim.x * blockDim.y;
+    const int H = (sx + 1) >> 1, CH = (cx + 1) >> 1;
     const size_t sxy = (size_t)sx * sy;
     const bool zinterior = pz > 0 && pz < cz - 1;
     // fine window origin (may be -1 at the low edge: those entries are never read)
@@ -159,9 +240,10 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
                 const int gx = gx0 + lx, gy = gy0 + ly;
                 real rv = (real)0;
                 if (gx >= 1 && gx < sx - 1 && gy >= 1 && gy < sy - 1) {
-                    const size_t i = gx + (size_t)gy * sx + (size_t)gz * sxy;
-                    rv = residual3d_point<real, MODE>(v[i - 1], v[i + 1], v[i - sx], v[i + sx], v[i - sxy], v[i + sxy],
-                                                      v[i], f[i], hx2, hy2, hz2);
+                    const size_t row = (size_t)gy * sx + (size_t)gz * sxy;
+                    const size_t i = row + L::pos(gx, H);
+                    rv = residual3d_point<real, MODE>(v[row + L::pos(gx - 1, H)], v[row + L::pos(gx + 1, H)], v[i - sx],
+                                                      v[i + sx], v[i - sxy], v[i + sxy], v[i], f[i], hx2, hy2, hz2);
                 }
                 res[k][ly][lx] = rv;
             }
@@ -172,7 +254,7 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
         const int ty = t / CTX, tx = t - ty * CTX;
         const int px = px0 + tx, py = py0 + ty;
         if (px >= cx || py >= cy) continue;
-        const size_t ci = px + (size_t)py * cx + (size_t)pz * cx * cy;
+        const size_t ci = L::pos(px, CH) + (size_t)py * cx + (size_t)pz * cx * cy;
         if (px == 0 || px == cx - 1 || py == 0 || py == cy - 1 || !zinterior) {
             coarse[ci] = (real)0;  // injection of a boundary residual, which is 0 (:704-705 then :113-119)
             continue;
@@ -203,7 +285,6 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const real* __restrict__ x, 
 static inline dim3 blk() { return dim3(64, 4, 1); }
 static inline dim3 grd(int nx, int ny, int nz) { return dim3(ceil_div(nx, 64), ceil_div(ny, 4), nz); }
 
-template <class real>
 static int check_n3(const int n[3], const char* what) {
     MGX_REQUIRE(n, MGX_ERR_INVALID, "%s: size array is NULL", what);
     for (int d = 0; d < 3; d++)
@@ -221,101 +302,132 @@ static int check_coarse3(const int fn[3], const int cn[3], const char* what) {
 }
 
 template <class real>
-int relax3d_two_pass(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles) {
-    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // N3/MultiGrid3D.cpp:498-500
-    if (n[0] < 3 || n[1] < 3 || n[2] < 3) return MGX_OK;
+static int relax3d_natural(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int ncycles) {
     dim3 g(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2);
     for (int k = 0; k < ncycles; k++)
-        for (int colour = 0; colour < 2; colour++) {
+        for (int colour = 0; colour < 2; colour++)
             hipLaunchKernelGGL((relax3d_colour_kernel<real>), g, blk(), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2,
                                hz2, colour);
+    return MGX_OK;
+}
+
+template <class real, int TY>
+static void launch_xs(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int colour,
+                      int zchunk) {
+    const int H = (n[0] + 1) / 2;
+    dim3 g(ceil_div(H - 1, 64), ceil_div(n[1] - 2, TY), ceil_div(n[2] - 2, zchunk));
+    hipLaunchKernelGGL((relax3d_xs_kernel<real, TY>), g, dim3(64, TY, 1), 0, ctx->compute, (const real*)v, v, f, n[0], n[1],
+                       n[2], hx2, hy2, hz2, colour, zchunk);
+}
+
+template <class real>
+static int relax3d_xsplit(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int ncycles) {
+    int ty = ctx->relax_ty, zchunk = ctx->relax_zchunk;
+    if (zchunk <= 0) {
+        // enough z-chunks to give every CU several blocks; long enough chunks to amortise the 2-plane prologue
+        const long long tiles = (long long)ceil_div((n[0] + 1) / 2 - 1, 64) * ceil_div(n[1] - 2, ty);
+        zchunk = 64;
+        while (zchunk > 8 && tiles * ceil_div(n[2] - 2, zchunk) < 8LL * ctx->num_cus) zchunk >>= 1;
+    }
+    for (int k = 0; k < ncycles; k++)
+        for (int colour = 0; colour < 2; colour++) {
+            switch (ty) {
+                case 1: launch_xs<real, 1>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
+                case 2: launch_xs<real, 2>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
+                case 8: launch_xs<real, 8>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
+                default: launch_xs<real, 4>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
+            }
         }
+    return MGX_OK;
+}
+
+template <class real, class L>
+int relax3d(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles) {
+    MGX_REQUIRE(ctx && v && f && h, MGX_ERR_INVALID, "relax3d: NULL argument");
+    int st = check_n3(n, "relax3d");
+    if (st) return st;
+    MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "relax3d: ncycles = %d < 0", ncycles);
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // N3/MultiGrid3D.cpp:498-500
+    if (L::xsplit) st = relax3d_xsplit<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles);
+    else st = relax3d_natural<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles);
+    if (st) return st;
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
 
-template <class real>
-int relax3d(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles) {
-    MGX_REQUIRE(ctx && v && f && h, MGX_ERR_INVALID, "relax3d: NULL argument");
-    int st = check_n3<real>(n, "relax3d");
-    if (st) return st;
-    MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "relax3d: ncycles = %d < 0", ncycles);
-    return relax3d_two_pass<real>(ctx, v, f, n, h, ncycles);
-}
-
-template <class real>
+template <class real, class L>
 int residual3d(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3], const real h[3], int mode) {
     MGX_REQUIRE(ctx && v && f && r && h, MGX_ERR_INVALID, "residual3d: NULL argument");
-    int st = check_n3<real>(n, "residual3d");
+    int st = check_n3(n, "residual3d");
     if (st) return st;
     MGX_REQUIRE(mode == MGX_RESIDUAL_REF_COMPAT || mode == MGX_RESIDUAL_CORRECT, MGX_ERR_INVALID, "residual3d: bad mode %d", mode);
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // N3/MultiGrid3D.cpp:687-689
     if (mode == MGX_RESIDUAL_REF_COMPAT)
-        hipLaunchKernelGGL((residual3d_kernel<real, 0>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, v, f, r, n[0], n[1],
+        hipLaunchKernelGGL((residual3d_kernel<real, L, 0>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, v, f, r, n[0], n[1],
                            n[2], hx2, hy2, hz2);
     else
-        hipLaunchKernelGGL((residual3d_kernel<real, 1>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, v, f, r, n[0], n[1],
+        hipLaunchKernelGGL((residual3d_kernel<real, L, 1>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, v, f, r, n[0], n[1],
                            n[2], hx2, hy2, hz2);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
 
-template <class real>
+template <class real, class L>
 int restrict3d(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse, const int cn[3]) {
     MGX_REQUIRE(ctx && fine && coarse, MGX_ERR_INVALID, "restrict3d: NULL argument");
-    int st = check_n3<real>(fn, "restrict3d");
+    int st = check_n3(fn, "restrict3d");
     if (st) return st;
     st = check_coarse3(fn, cn, "restrict3d");
     if (st) return st;
-    hipLaunchKernelGGL((restrict3d_kernel<real>), grd(cn[0], cn[1], cn[2]), blk(), 0, ctx->compute, fine, fn[0], fn[1],
+    hipLaunchKernelGGL((restrict3d_kernel<real, L>), grd(cn[0], cn[1], cn[2]), blk(), 0, ctx->compute, fine, fn[0], fn[1],
                        coarse, cn[0], cn[1], cn[2]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
 
-template <class real, bool ADD>
+template <class real, class L, bool ADD>
 int interpolate3d(mgx_ctx* ctx, real* fine, const int fn[3], const real* coarse, const int cn[3]) {
     MGX_REQUIRE(ctx && fine && coarse, MGX_ERR_INVALID, "interpolate3d: NULL argument");
-    int st = check_n3<real>(fn, "interpolate3d");
+    int st = check_n3(fn, "interpolate3d");
     if (st) return st;
     st = check_coarse3(fn, cn, "interpolate3d");
     if (st) return st;
-    hipLaunchKernelGGL((interpolate3d_kernel<real, ADD>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute, fine,
-                       fn[0], fn[1], fn[2], coarse, cn[0], cn[1]);
+    hipLaunchKernelGGL((interpolate3d_kernel<real, L, ADD>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute,
+                       fine, fn[0], fn[1], fn[2], coarse, cn[0], cn[1]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
 
-template <class real>
+template <class real, class L>
 int correct3d(mgx_ctx* ctx, real* fine, const int fn[3], const real* err, const int en[3]) {
     MGX_REQUIRE(ctx && fine && err && en, MGX_ERR_INVALID, "apply_correction3d: NULL argument");
-    int st = check_n3<real>(fn, "apply_correction3d");
+    int st = check_n3(fn, "apply_correction3d");
     if (st) return st;
     for (int d = 0; d < 3; d++)  // N3/MultiGrid3D.cpp:660-662
         MGX_REQUIRE(fn[d] == en[d], MGX_ERR_SIZE, "apply_correction3d: size[%d] %d != %d", d, fn[d], en[d]);
-    hipLaunchKernelGGL((correct3d_kernel<real>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute, fine, err,
+    hipLaunchKernelGGL((correct3d_kernel<real, L>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute, fine, err,
                        fn[0], fn[1], fn[2]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
 
-template <class real>
+template <class real, class L>
 int set3d(mgx_ctx* ctx, real* g, const int n[3], real value, int modify_boundaries) {
     MGX_REQUIRE(ctx && g, MGX_ERR_INVALID, "set3d: NULL argument");
-    int st = check_n3<real>(n, "set3d");
+    int st = check_n3(n, "set3d");
     if (st) return st;
     const int lo = modify_boundaries ? 0 : 1;
-    hipLaunchKernelGGL((set3d_kernel<real>), grd(n[0] - 2 * lo, n[1] - 2 * lo, n[2] - 2 * lo), blk(), 0, ctx->compute, g,
+    hipLaunchKernelGGL((set3d_kernel<real, L>), grd(n[0] - 2 * lo, n[1] - 2 * lo, n[2] - 2 * lo), blk(), 0, ctx->compute, g,
                        n[0], n[1], n[2], value, lo);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
 
-template <class real>
+template <class real, class L>
 int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[3], const real h[3], int mode,
                         real* coarse_f, const int cn[3]) {
     MGX_REQUIRE(ctx && v && f && h && coarse_f, MGX_ERR_INVALID, "residual_restrict3d: NULL argument");
-    int st = check_n3<real>(n, "residual_restrict3d");
+    int st = check_n3(n, "residual_restrict3d");
     if (st) return st;
     st = check_coarse3(n, cn, "residual_restrict3d");
     if (st) return st;
@@ -325,19 +437,19 @@ int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[
     constexpr int CTX = 32, CTY = 8;
     dim3 g(ceil_div(cn[0], CTX), ceil_div(cn[1], CTY), cn[2]);
     if (mode == MGX_RESIDUAL_REF_COMPAT)
-        hipLaunchKernelGGL((residual_restrict3d_kernel<real, 0, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1], n[2],
-                           hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2]);
+        hipLaunchKernelGGL((residual_restrict3d_kernel<real, L, 0, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1],
+                           n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2]);
     else
-        hipLaunchKernelGGL((residual_restrict3d_kernel<real, 1, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1], n[2],
-                           hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2]);
+        hipLaunchKernelGGL((residual_restrict3d_kernel<real, L, 1, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1],
+                           n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
 
-template <class real>
+template <class real, class L>
 int init_f3d(mgx_ctx* ctx, real* f, const int n[3], double c, const double* tx, const double* ty, const double* tz) {
     MGX_REQUIRE(ctx && f && tx && ty && tz, MGX_ERR_INVALID, "init_f3d: NULL argument");
-    int st = check_n3<real>(n, "init_f3d");
+    int st = check_n3(n, "init_f3d");
     if (st) return st;
     const size_t cnt = (size_t)n[0] + n[1] + n[2];
     void* ws = nullptr;
@@ -347,10 +459,21 @@ int init_f3d(mgx_ctx* ctx, real* f, const int n[3], double c, const double* tx, 
     MGX_HIP(hipMemcpyAsync(d, tx, n[0] * sizeof(double), hipMemcpyHostToDevice, ctx->compute));
     MGX_HIP(hipMemcpyAsync(d + n[0], ty, n[1] * sizeof(double), hipMemcpyHostToDevice, ctx->compute));
     MGX_HIP(hipMemcpyAsync(d + n[0] + n[1], tz, n[2] * sizeof(double), hipMemcpyHostToDevice, ctx->compute));
-    hipLaunchKernelGGL((init_f3d_kernel<real>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, f, n[0], n[1], n[2], c, d,
+    hipLaunchKernelGGL((init_f3d_kernel<real, L>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, f, n[0], n[1], n[2], c, d,
                        d + n[0], d + n[0] + n[1]);
     MGX_LAUNCH_CHECK();
     MGX_HIP(hipStreamSynchronize(ctx->compute));  // host tables may be freed by the caller
+    return MGX_OK;
+}
+
+template <class real, class LS, class LD>
+int relayout3d(mgx_ctx* ctx, const real* src, real* dst, const int n[3]) {
+    MGX_REQUIRE(ctx && src && dst, MGX_ERR_INVALID, "relayout3d: NULL argument");
+    MGX_REQUIRE(src != dst, MGX_ERR_INVALID, "relayout3d: in-place conversion is not supported");
+    int st = check_n3(n, "relayout3d");
+    if (st) return st;
+    hipLaunchKernelGGL((relayout3d_kernel<real, LS, LD>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, src, dst, n[0], n[1]);
+    MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
 
@@ -375,45 +498,69 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
 
 }  // namespace mgx
 
-#define MGX_DEFINE_OPS3D(SFX, real)                                                                              \
-    int mgx3d_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3],              \
-                          int ncycles) {                                                                         \
-        return mgx::relax3d<real>(ctx, v, f, n, h, ncycles);                                                     \
+#define MGX_DEFINE_OPS3D(PFX, L, SFX, real)                                                                      \
+    int PFX##relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles) {    \
+        return mgx::relax3d<real, L>(ctx, v, f, n, h, ncycles);                                                  \
     }                                                                                                            \
-    int mgx3d_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3], const real h[3], \
-                             int mode) {                                                                         \
-        return mgx::residual3d<real>(ctx, v, f, r, n, h, mode);                                                  \
+    int PFX##residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3], const real h[3], \
+                            int mode) {                                                                          \
+        return mgx::residual3d<real, L>(ctx, v, f, r, n, h, mode);                                               \
     }                                                                                                            \
-    int mgx3d_restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse, const int cn[3]) {    \
-        return mgx::restrict3d<real>(ctx, fine, fn, coarse, cn);                                                 \
+    int PFX##restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse, const int cn[3]) {     \
+        return mgx::restrict3d<real, L>(ctx, fine, fn, coarse, cn);                                              \
     }                                                                                                            \
-    int mgx3d_interpolate_##SFX(mgx_ctx* ctx, real* fine, const int fn[3], const real* coarse, const int cn[3]) { \
-        return mgx::interpolate3d<real, false>(ctx, fine, fn, coarse, cn);                                       \
+    int PFX##interpolate_##SFX(mgx_ctx* ctx, real* fine, const int fn[3], const real* coarse, const int cn[3]) {  \
+        return mgx::interpolate3d<real, L, false>(ctx, fine, fn, coarse, cn);                                    \
     }                                                                                                            \
-    int mgx3d_apply_correction_##SFX(mgx_ctx* ctx, real* fine, const int fn[3], const real* err,                 \
-                                     const int en[3]) {                                                          \
-        return mgx::correct3d<real>(ctx, fine, fn, err, en);                                                     \
+    int PFX##apply_correction_##SFX(mgx_ctx* ctx, real* fine, const int fn[3], const real* err, const int en[3]) { \
+        return mgx::correct3d<real, L>(ctx, fine, fn, err, en);                                                  \
     }                                                                                                            \
-    int mgx3d_set_##SFX(mgx_ctx* ctx, real* grid, const int n[3], real value, int modify_boundaries) {           \
-        return mgx::set3d<real>(ctx, grid, n, value, modify_boundaries);                                         \
+    int PFX##set_##SFX(mgx_ctx* ctx, real* grid, const int n[3], real value, int modify_boundaries) {            \
+        return mgx::set3d<real, L>(ctx, grid, n, value, modify_boundaries);                                      \
     }                                                                                                            \
-    int mgx3d_residual_restrict_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[3],                \
-                                      const real h[3], int mode, real* coarse_f, const int cn[3]) {              \
-        return mgx::residual_restrict3d<real>(ctx, v, f, n, h, mode, coarse_f, cn);                              \
+    int PFX##residual_restrict_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[3], const real h[3], \
+                                     int mode, real* coarse_f, const int cn[3]) {                                \
+        return mgx::residual_restrict3d<real, L>(ctx, v, f, n, h, mode, coarse_f, cn);                           \
     }                                                                                                            \
-    int mgx3d_interpolate_correct_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,             \
-                                        const int cn[3]) {                                                       \
-        return mgx::interpolate3d<real, true>(ctx, v, n, coarse_v, cn);                                          \
+    int PFX##interpolate_correct_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,              \
+                                       const int cn[3]) {                                                        \
+        return mgx::interpolate3d<real, L, true>(ctx, v, n, coarse_v, cn);                                       \
     }                                                                                                            \
-    int mgx3d_init_f_##SFX(mgx_ctx* ctx, real* f, const int n[3], double c, const double* host_tx,               \
-                           const double* host_ty, const double* host_tz) {                                       \
-        return mgx::init_f3d<real>(ctx, f, n, c, host_tx, host_ty, host_tz);                                     \
+    int PFX##init_f_##SFX(mgx_ctx* ctx, real* f, const int n[3], double c, const double* host_tx,                \
+                          const double* host_ty, const double* host_tz) {                                        \
+        return mgx::init_f3d<real, L>(ctx, f, n, c, host_tx, host_ty, host_tz);                                  \
+    }
+
+#define MGX_DEFINE_MISC3D(SFX, real)                                                                             \
+    int mgx3dxs_pack_##SFX(mgx_ctx* ctx, const real* natural, real* xsplit, const int n[3]) {                    \
+        return mgx::relayout3d<real, mgx::Natural, mgx::XSplit>(ctx, natural, xsplit, n);                        \
+    }                                                                                                            \
+    int mgx3dxs_unpack_##SFX(mgx_ctx* ctx, const real* xsplit, real* natural, const int n[3]) {                  \
+        return mgx::relayout3d<real, mgx::XSplit, mgx::Natural>(ctx, xsplit, natural, n);                        \
     }                                                                                                            \
     int mgx_norm2_##SFX(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {                         \
         return mgx::norm2<real>(ctx, x, count, host_sumsq);                                                      \
     }
 
 extern "C" {
-MGX_DEFINE_OPS3D(f32, float)
-MGX_DEFINE_OPS3D(f64, double)
+MGX_DEFINE_OPS3D(mgx3d_, mgx::Natural, f32, float)
+MGX_DEFINE_OPS3D(mgx3d_, mgx::Natural, f64, double)
+MGX_DEFINE_OPS3D(mgx3dxs_, mgx::XSplit, f32, float)
+MGX_DEFINE_OPS3D(mgx3dxs_, mgx::XSplit, f64, double)
+MGX_DEFINE_MISC3D(f32, float)
+MGX_DEFINE_MISC3D(f64, double)
+
+int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
+    MGX_REQUIRE(ctx && name, MGX_ERR_INVALID, "set_param: NULL argument");
+    if (!strcmp(name, "relax3d.ty")) {
+        MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.ty must be 1, 2, 4 or 8");
+        ctx->relax_ty = value;
+    } else if (!strcmp(name, "relax3d.zchunk")) {
+        MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "relax3d.zchunk must be >= 0 (0 = automatic)");
+        ctx->relax_zchunk = value;
+    } else {
+        return mgx::fail(MGX_ERR_INVALID, "set_param: unknown parameter '%s'", name);
+    }
+    return MGX_OK;
+}
 }

@@ -11,6 +11,16 @@
 
 namespace mgx {
 
+// Array layouts: position of column x inside its x-row (H = (sx+1)/2).
+struct Natural {  // the reference layout: idx = x + y*sx + z*sx*sy   (N3/MultiGrid3D.cpp:531)
+    static constexpr bool xsplit = false;
+    static __device__ __forceinline__ int pos(int x, int) { return x; }
+};
+struct XSplit {  // even-x half [0, H) then odd-x half [H, sx) of every row; rows/planes as in Natural
+    static constexpr bool xsplit = true;
+    static __device__ __forceinline__ int pos(int x, int H) { return (x >> 1) + (x & 1) * H; }
+};
+
 // MultiGrid3D::Relax per-point update.                      N3/MultiGrid3D.cpp:532 (=:561)
 //   v = (O*(hy2*hz2)+E*(hy2*hz2) + N*(hx2*hz2)+S*(hx2*hz2) + D*(hx2*hy2)+U*(hx2*hy2)
 //        - f*hx2*hy2*hz2) / (2*(hy2*hz2 + hx2*hz2 + hx2*hy2))

@@ -81,6 +81,9 @@ class Context:
     def free(self, p):
         check(lib.mgx_free(self._h, p))
 
+    def set_param(self, name, value):
+        check(lib.mgx_ctx_set_param(self._h, name.encode(), C.c_int(int(value))))
+
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)
         p = self.malloc(arr.nbytes)
@@ -119,23 +122,43 @@ class Context:
 
 
 # --------------------------------------------------------------------------- raw operators
-class _Ops:
-    """Per-operator entry points of mgx.h on numpy arrays: upload, launch, download.  Used by the
-    parity tests; the cycle code in C keeps everything resident instead."""
+def xs_pack(a):
+    """numpy restatement of the x-split layout: every x-row as its even-x half then its odd-x half"""
+    a = np.asarray(a)
+    return np.ascontiguousarray(np.concatenate([a[..., 0::2], a[..., 1::2]], axis=-1))
 
-    def __init__(self, dim):
+
+def xs_unpack(a):
+    a = np.asarray(a)
+    H = (a.shape[-1] + 1) // 2
+    out = np.empty_like(a)
+    out[..., 0::2] = a[..., :H]
+    out[..., 1::2] = a[..., H:]
+    return out
+
+
+class _Ops:
+    """Per-operator entry points of mgx.h on numpy arrays (reference layout): upload, launch, download.
+    Used by the parity tests; the cycle code in C keeps everything resident instead.  With
+    xsplit=True the arrays are converted to the x-split layout on the host and the mgx3dxs_
+    twins are called."""
+
+    def __init__(self, dim, xsplit=False):
         self.dim = dim
-        self.p = "mgx%dd_" % dim
+        self.xsplit = xsplit
+        self.p = ("mgx%ddxs_" if xsplit else "mgx%dd_") % dim
 
     def _fn(self, name, dtype):
         s, ct = _ct(dtype)
         return getattr(lib, self.p + name + "_" + s), ct
 
     def _run(self, ctx, arrays, call, out_index, out_shape, dtype):
-        ptrs = [ctx.to_device(np.ascontiguousarray(a, dtype=dtype)) if a is not None else None for a in arrays]
+        conv = xs_pack if self.xsplit else (lambda a: a)
+        ptrs = [ctx.to_device(conv(np.ascontiguousarray(a, dtype=dtype))) if a is not None else None for a in arrays]
         try:
             check(call(*ptrs))
-            return ctx.to_host(ptrs[out_index], out_shape, dtype)
+            out = ctx.to_host(ptrs[out_index], out_shape, dtype)
+            return xs_unpack(out) if self.xsplit else out
         finally:
             for p in ptrs:
                 if p is not None:
@@ -168,8 +191,31 @@ class _Ops:
 
 
 class _Ops3D(_Ops):
-    def __init__(self):
-        super().__init__(3)
+    def __init__(self, xsplit=False):
+        super().__init__(3, xsplit)
+
+    def pack(self, ctx, a):
+        """device-side Natural -> XSplit conversion (mgx3dxs_pack), returned as stored"""
+        s, _ = _ct(a.dtype)
+        n = tuple(reversed(a.shape))
+        src, dst = ctx.to_device(a), ctx.malloc(a.nbytes)
+        try:
+            check(getattr(lib, "mgx3dxs_pack_" + s)(ctx._h, src, dst, _ip(n)))
+            return ctx.to_host(dst, a.shape, a.dtype)
+        finally:
+            ctx.free(src)
+            ctx.free(dst)
+
+    def unpack(self, ctx, a):
+        s, _ = _ct(a.dtype)
+        n = tuple(reversed(a.shape))
+        src, dst = ctx.to_device(a), ctx.malloc(a.nbytes)
+        try:
+            check(getattr(lib, "mgx3dxs_unpack_" + s)(ctx._h, src, dst, _ip(n)))
+            return ctx.to_host(dst, a.shape, a.dtype)
+        finally:
+            ctx.free(src)
+            ctx.free(dst)
 
     def relax(self, ctx, v, f, n, rng, ncycles, dtype=None):
         dtype = dtype or v.dtype
@@ -235,6 +281,7 @@ class _Ops2D(_Ops):
 
 
 ops3d = _Ops3D()
+ops3dxs = _Ops3D(xsplit=True)
 ops2d = _Ops2D()
 
 
@@ -248,7 +295,7 @@ def _grid3_struct(ct):
 
     class MultiGrid3D(C.Structure):
         _fields_ = [("grids3D", C.POINTER(C.POINTER(Grid3D))), ("numGrids", C.c_int), ("maxGrids", C.c_int),
-                    ("ctx", C.c_void_p), ("residual_mode", C.c_int), ("fuse", C.c_int)]
+                    ("ctx", C.c_void_p), ("residual_mode", C.c_int), ("fuse", C.c_int), ("layout", C.c_int)]
 
     return Grid3D, MultiGrid3D
 
@@ -319,14 +366,16 @@ class MultiGrid3D(_MGBase):
     """MultiGrid3D(finestGridSizeXYZ, range) of the reference (N3/MultiGrid3D.h:6-33) on one MI355X."""
     _prefix = "mgMultiGrid3D"
 
-    def __init__(self, ctx, finestGridSizeXYZ, rng, dtype=np.float64, nlevels=0, residual_mode=REF_COMPAT, fuse=True):
+    def __init__(self, ctx, finestGridSizeXYZ, rng, dtype=np.float64, nlevels=0, residual_mode=REF_COMPAT, fuse=True,
+                 layout="xsplit"):
         self.ctx = ctx
         self.dtype = np.dtype(dtype)
         self._sfx, self._ct = _ct(dtype)
         self._G, self._M = _grid3_struct(self._ct)
         self._mg = C.POINTER(self._M)()
-        fn = getattr(lib, "mgMultiGrid3D_%s_create" % self._sfx)
-        check(fn(ctx._h, _ip(finestGridSizeXYZ), _rp(rng, self._ct), C.byref(self._mg)))
+        fn = getattr(lib, "mgMultiGrid3D_%s_create_layout" % self._sfx)
+        lay = {"natural": 0, "xsplit": 1}[layout]
+        check(fn(ctx._h, _ip(finestGridSizeXYZ), _rp(rng, self._ct), C.c_int(lay), C.byref(self._mg)))
         if nlevels:
             self.numGrids = nlevels
         self._mg.contents.residual_mode = int(residual_mode)
@@ -342,9 +391,9 @@ class MultiGrid3D(_MGBase):
         self._call("Relax", self._mg.contents.grids3D[gridID], C.c_int(ncycles))
 
     def CalculateResidual(self, gridID):
-        r = C.c_void_p()
-        self._call("CalculateResidual", self._mg.contents.grids3D[gridID], C.byref(r))
-        return self.ctx.to_host(r, _shape(self.size(gridID)), self.dtype)
+        out = np.empty(_shape(self.size(gridID)), self.dtype)
+        self._call("download_residual", C.c_int(gridID), out.ctypes.data_as(C.c_void_p))
+        return out
 
     def ResidualNorm(self, gridID=0):
         out = C.c_double()
@@ -357,6 +406,13 @@ class MultiGrid3D(_MGBase):
     def setToValue_v(self, gridID, value, modifyBoundaries):
         g = self.grid(gridID)
         self._call("setToValue", C.c_void_p(g.d_v), _ip(g.sizeXYZ), self._ct(value), C.c_int(int(modifyBoundaries)))
+
+    def interpolate_correct(self, gridID):
+        """v[gridID] += Interpolate(v[gridID+1]) on the interior (the fused VCycle step)."""
+        g0, g1 = self.grid(gridID), self.grid(gridID + 1)
+        pfx = "mgx3dxs_" if self._mg.contents.layout else "mgx3d_"
+        check(getattr(lib, pfx + "interpolate_correct_" + self._sfx)(self.ctx._h, C.c_void_p(g0.d_v), _ip(g0.sizeXYZ),
+                                                                     C.c_void_p(g1.d_v), _ip(g1.sizeXYZ)))
 
     def upload_v(self, gridID, arr):
         arr = np.ascontiguousarray(arr, self.dtype)

@@ -33,30 +33,39 @@ def assert_f64(a, b):
 
 
 # ------------------------------------------------------------------ 3D per-operator, fp32 golden
+OPS3 = {"natural": P.ops3d, "xsplit": P.ops3dxs}  # the reference layout and the device-internal x-split layout
+
+
+@pytest.mark.parametrize("layout", ["natural", "xsplit"])
 @pytest.mark.parametrize("n", [5, 9, 17])
-def test_3d_ops_f32_vs_reference_fixtures(ctx, n):
+def test_3d_ops_f32_vs_reference_fixtures(ctx, n, layout):
+    ops = OPS3[layout]
     g = load_golden("ops3d_n%d.npz" % n)
     n3, rg, v, f, c = g["n"].tolist(), g["range"].tolist(), g["v"], g["f"], g["c"]
-    assert bits_equal(P.ops3d.relax(ctx, v, f, n3, rg, 1), g["relax1"])
-    assert bits_equal(P.ops3d.relax(ctx, v, f, n3, rg, 3), g["relax3"])
-    assert bits_equal(P.ops3d.residual(ctx, v, f, n3, rg), g["residual"])
-    assert bits_equal(P.ops3d.restrict(ctx, v, n3), g["restrict"])
-    assert bits_equal(P.ops3d.interpolate(ctx, v, n3, c), g["interpolate"])
-    assert bits_equal(P.ops3d.apply_correction(ctx, v, n3, f), g["correct"])
-    assert bits_equal(P.ops3d.set(ctx, v, n3, 2.5, False), g["set_interior"])
-    assert bits_equal(P.ops3d.set(ctx, v, n3, 2.5, True), g["set_all"])
+    assert bits_equal(ops.relax(ctx, v, f, n3, rg, 1), g["relax1"])
+    assert bits_equal(ops.relax(ctx, v, f, n3, rg, 3), g["relax3"])
+    assert bits_equal(ops.residual(ctx, v, f, n3, rg), g["residual"])
+    assert bits_equal(ops.restrict(ctx, v, n3), g["restrict"])
+    assert bits_equal(ops.interpolate(ctx, v, n3, c), g["interpolate"])
+    assert bits_equal(ops.apply_correction(ctx, v, n3, f), g["correct"])
+    assert bits_equal(ops.set(ctx, v, n3, 2.5, False), g["set_interior"])
+    assert bits_equal(ops.set(ctx, v, n3, 2.5, True), g["set_all"])
     # fused forms == the two reference calls they replace
-    assert bits_equal(P.ops3d.residual_restrict(ctx, v, f, n3, rg), O.restrict3d(n3, g["residual"]))
-    assert bits_equal(P.ops3d.interpolate_correct(ctx, v, n3, c), O.correct3d(n3, v, O.interpolate3d(n3, v, c)))
+    assert bits_equal(ops.residual_restrict(ctx, v, f, n3, rg), O.restrict3d(n3, g["residual"]))
+    assert bits_equal(ops.interpolate_correct(ctx, v, n3, c), O.correct3d(n3, v, O.interpolate3d(n3, v, c)))
+    if layout == "xsplit":
+        return
     # cycles through the C host layer
     assert bits_equal(P.solve3d(ctx, v, f, rg, ncycles=1), g["vcycle22"])
     assert bits_equal(P.solve3d(ctx, v, f, rg, fmg=True, v0=1), g["fmg122"])
 
 
-@pytest.mark.parametrize("n3", [(9, 9, 9), (33, 17, 9), (65, 33, 129), (129, 129, 5)])
+@pytest.mark.parametrize("layout", ["natural", "xsplit"])
+@pytest.mark.parametrize("n3", [(9, 9, 9), (33, 17, 9), (65, 33, 129), (129, 129, 5), (257, 9, 17)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_3d_ops_vs_oracle_random(ctx, n3, dtype):
+def test_3d_ops_vs_oracle_random(ctx, n3, dtype, layout):
     """anisotropic sizes and ranges: catches axis swaps the symmetric test problem cannot"""
+    ops = OPS3[layout]
     rng = np.random.default_rng(sum(n3))
     rg = [-1, 1, 0, 2, 0.5, 3]
     v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
@@ -64,27 +73,55 @@ def test_3d_ops_vs_oracle_random(ctx, n3, dtype):
     c = rng.uniform(-1, 1, O.shape(O.csize(n3))).astype(dtype)
     eq = bits_equal
     for k in (1, 2):
-        assert eq(P.ops3d.relax(ctx, v, f, n3, rg, k), O.relax3d(n3, rg, v, f, k, dtype=dtype))
+        assert eq(ops.relax(ctx, v, f, n3, rg, k), O.relax3d(n3, rg, v, f, k, dtype=dtype))
     for mode in (P.REF_COMPAT, P.CORRECT):
         r = O.residual3d(n3, rg, v, f, mode, dtype=dtype)
-        assert eq(P.ops3d.residual(ctx, v, f, n3, rg, mode), r)
-        assert eq(P.ops3d.residual_restrict(ctx, v, f, n3, rg, mode), O.restrict3d(n3, r, dtype=dtype))
-    assert eq(P.ops3d.restrict(ctx, v, n3), O.restrict3d(n3, v, dtype=dtype))
-    assert eq(P.ops3d.interpolate(ctx, v, n3, c), O.interpolate3d(n3, v, c, dtype=dtype))
-    assert eq(P.ops3d.interpolate_correct(ctx, v, n3, c), O.correct3d(n3, v, O.interpolate3d(n3, v, c, dtype=dtype), dtype=dtype))
-    assert eq(P.ops3d.apply_correction(ctx, v, n3, f), O.correct3d(n3, v, f, dtype=dtype))
+        assert eq(ops.residual(ctx, v, f, n3, rg, mode), r)
+        assert eq(ops.residual_restrict(ctx, v, f, n3, rg, mode), O.restrict3d(n3, r, dtype=dtype))
+    assert eq(ops.restrict(ctx, v, n3), O.restrict3d(n3, v, dtype=dtype))
+    assert eq(ops.interpolate(ctx, v, n3, c), O.interpolate3d(n3, v, c, dtype=dtype))
+    assert eq(ops.interpolate_correct(ctx, v, n3, c), O.correct3d(n3, v, O.interpolate3d(n3, v, c, dtype=dtype), dtype=dtype))
+    assert eq(ops.apply_correction(ctx, v, n3, f), O.correct3d(n3, v, f, dtype=dtype))
     for b in (0, 1):
-        assert eq(P.ops3d.set(ctx, v, n3, -7.25, b), O.set3d(n3, v, -7.25, b, dtype=dtype))
+        assert eq(ops.set(ctx, v, n3, -7.25, b), O.set3d(n3, v, -7.25, b, dtype=dtype))
 
 
-def test_3d_smallest_grid_and_zero_sweeps(ctx):
+@pytest.mark.parametrize("layout", ["natural", "xsplit"])
+def test_3d_smallest_grid_and_zero_sweeps(ctx, layout):
+    ops = OPS3[layout]
     n3, rg = [3, 3, 3], R3
     rng = np.random.default_rng(3)
     v = rng.uniform(-1, 1, (3, 3, 3))
     f = rng.uniform(-1, 1, (3, 3, 3))
-    assert_f64(P.ops3d.relax(ctx, v, f, n3, rg, 4), O.relax3d(n3, rg, v, f, 4, dtype=np.float64))
-    assert bits_equal(P.ops3d.relax(ctx, v, f, n3, rg, 0), v)
-    assert_f64(P.ops3d.residual(ctx, v, f, n3, rg), O.residual3d(n3, rg, v, f, dtype=np.float64))
+    assert_f64(ops.relax(ctx, v, f, n3, rg, 4), O.relax3d(n3, rg, v, f, 4, dtype=np.float64))
+    assert bits_equal(ops.relax(ctx, v, f, n3, rg, 0), v)
+    assert_f64(ops.residual(ctx, v, f, n3, rg), O.residual3d(n3, rg, v, f, dtype=np.float64))
+
+
+def test_3d_xsplit_pack_unpack(ctx):
+    """device Natural <-> XSplit conversion against the numpy restatement of the layout"""
+    rng = np.random.default_rng(11)
+    for shape in ((3, 3, 3), (5, 9, 17), (9, 5, 129)):
+        for dtype in (np.float32, np.float64):
+            a = rng.uniform(-1, 1, shape).astype(dtype)
+            assert bits_equal(P.ops3d.pack(ctx, a), P.xs_pack(a))
+            assert bits_equal(P.ops3d.unpack(ctx, P.xs_pack(a)), a)
+
+
+@pytest.mark.parametrize("ty,zchunk", [(1, 1), (2, 3), (4, 0), (8, 64), (4, 7)])
+def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, zchunk):
+    """rows per block / z-chunk length of the marching smoother are speed knobs only"""
+    n3, rg = (65, 33, 41), [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(5)
+    v = rng.uniform(-1, 1, O.shape(n3))
+    f = rng.uniform(-1, 1, O.shape(n3))
+    ctx.set_param("relax3d.ty", ty)
+    ctx.set_param("relax3d.zchunk", zchunk)
+    try:
+        assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 3), O.relax3d(n3, rg, v, f, 3, dtype=np.float64))
+    finally:
+        ctx.set_param("relax3d.ty", 4)
+        ctx.set_param("relax3d.zchunk", 0)
 
 
 def test_3d_size_violations_return_status(ctx):
@@ -104,14 +141,15 @@ def test_3d_size_violations_return_status(ctx):
 @pytest.mark.parametrize("name", ["3d_n9_fmg122", "3d_n17_fmg122", "3d_n33_vcycle22", "3d_n65_vcycle22",
                                   "3d_n129_relax10", "3d_n257_vcycle22_6lev", "3d_n257_relax4"])
 @pytest.mark.parametrize("fuse", [True, False])
-def test_3d_reference_known_answers_f32(ctx, known_answers, name, fuse):
+@pytest.mark.parametrize("layout", ["natural", "xsplit"])
+def test_3d_reference_known_answers_f32(ctx, known_answers, name, fuse, layout):
     """analytic InitF on the device (host sin tables) + cycles == the unmodified reference, bit for bit;
     3d_n257_vcycle22_6lev is BASELINE.json configs[2] (in the reference's own fp32)."""
     ka = known_answers[name]
     n = ka["n"]
     if fuse is False and n > 129:
         pytest.skip("unfused path covered at smaller sizes")
-    mg = P.MultiGrid3D(ctx, [n] * 3, R3, np.float32, nlevels=ka.get("nlevels", 0), fuse=fuse)
+    mg = P.MultiGrid3D(ctx, [n] * 3, R3, np.float32, nlevels=ka.get("nlevels", 0), fuse=fuse, layout=layout)
     if ka["mode"] == 0:
         mg.VCycle(0, ka["v1"], ka["v2"])
     else:
@@ -124,9 +162,10 @@ def test_3d_reference_known_answers_f32(ctx, known_answers, name, fuse):
 
 @pytest.mark.parametrize("n,nlev", [(33, 0), (65, 4), (129, 0)])
 @pytest.mark.parametrize("mode", [P.REF_COMPAT, P.CORRECT])
-def test_3d_cycles_f64_vs_oracle(ctx, n, nlev, mode):
+@pytest.mark.parametrize("layout", ["natural", "xsplit"])
+def test_3d_cycles_f64_vs_oracle(ctx, n, nlev, mode, layout):
     for fmg in (False, True):
-        mg = P.MultiGrid3D(ctx, [n] * 3, R3, np.float64, nlevels=nlev, residual_mode=mode)
+        mg = P.MultiGrid3D(ctx, [n] * 3, R3, np.float64, nlevels=nlev, residual_mode=mode, layout=layout)
         if fmg:
             mg.FullMultiGridVCycle(0, 1, 2, 2)
         else:
@@ -180,10 +219,8 @@ def test_3d_full_size_513_sweep_and_properties(ctx):
     mg.close()
     mg = P.MultiGrid3D(ctx, [n] * 3, R3, np.float64, nlevels=2)
     mg.upload_v(0, got)
-    g0, g1 = mg.grid(0), mg.grid(1)
-    P.check(P.lib.mgx3d_set_f64(ctx._h, C.c_void_p(g1.d_v), (C.c_int * 3)(*g1.sizeXYZ), C.c_double(0.0), 1))
-    P.check(P.lib.mgx3d_interpolate_correct_f64(ctx._h, C.c_void_p(g0.d_v), (C.c_int * 3)(*g0.sizeXYZ),
-                                                C.c_void_p(g1.d_v), (C.c_int * 3)(*g1.sizeXYZ)))
+    mg.setToValue_v(1, 0.0, True)
+    mg.interpolate_correct(0)
     assert bits_equal(mg.download_v(0), got)
     mg.close()
 
