@@ -16,6 +16,7 @@ struct mgx_ctx {
     hipEvent_t ev_comm = nullptr;     // comm -> compute ordering
     int relax_ty = 4;      // rows per block of relax3d_xs_kernel (tuning)
     int relax_zchunk = 0;  // planes per z-chunk, 0 = automatic
+    int relax_xcd = 1;     // XCD-aware block -> tile mapping
     void* scratch = nullptr;  // small device workspace (reductions, tables)
     size_t scratch_bytes = 0;
     void* rccl_comm = nullptr;  // ncclComm_t

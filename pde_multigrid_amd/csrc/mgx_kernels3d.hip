@@ -72,12 +72,22 @@ __global__ void __launch_bounds__(256) relax3d_colour_kernel(real* __restrict__ 
 template <class real, int TY>
 __global__ void __launch_bounds__(64 * TY)
     relax3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
-                      int sz, real hx2, real hy2, real hz2, int colour, int zchunk) {
+                      int sz, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy, int xcd_swizzle) {
     const int H = (sx + 1) >> 1;
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    const int y = 1 + blockIdx.y * TY + threadIdx.y;
+    // 1-D grid decoded to (bx, by, bz).  Workgroups are dealt round-robin over the 8 XCDs
+    // (MI355X_MICROARCH.md: blocks b and b+8 share an XCD); with xcd_swizzle every XCD gets one
+    // contiguous run of tiles, so tiles adjacent in y / z (which re-read each other's edge rows and
+    // planes) share an L2.  Speed only: any mapping gives the same result.
+    unsigned b = blockIdx.x;
+    if (xcd_swizzle) {
+        const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
+        b = k * per + (k < rem ? k : rem) + (b >> 3);
+    }
+    const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
+    const int j = bx * 64 + threadIdx.x;
+    const int y = 1 + by * TY + threadIdx.y;
     if (y >= sy - 1 || j >= H - 1) return;  // x = 2j+q <= sx-2 needs j <= H-2
-    const int z0 = 1 + blockIdx.z * zchunk;
+    const int z0 = 1 + bz * zchunk;
     const int z1 = min(z0 + zchunk, sz - 1);
     if (z0 >= z1) return;
     const size_t sxy = (size_t)sx * sy;
@@ -315,9 +325,9 @@ template <class real, int TY>
 static void launch_xs(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int colour,
                       int zchunk) {
     const int H = (n[0] + 1) / 2;
-    dim3 g(ceil_div(H - 1, 64), ceil_div(n[1] - 2, TY), ceil_div(n[2] - 2, zchunk));
-    hipLaunchKernelGGL((relax3d_xs_kernel<real, TY>), g, dim3(64, TY, 1), 0, ctx->compute, (const real*)v, v, f, n[0], n[1],
-                       n[2], hx2, hy2, hz2, colour, zchunk);
+    const int gx = ceil_div(H - 1, 64), gy = ceil_div(n[1] - 2, TY), gz = ceil_div(n[2] - 2, zchunk);
+    hipLaunchKernelGGL((relax3d_xs_kernel<real, TY>), dim3((unsigned)gx * gy * gz), dim3(64, TY, 1), 0, ctx->compute,
+                       (const real*)v, v, f, n[0], n[1], n[2], hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
 }
 
 template <class real>
@@ -555,6 +565,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "relax3d.ty")) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.ty must be 1, 2, 4 or 8");
         ctx->relax_ty = value;
+    } else if (!strcmp(name, "relax3d.xcd")) {
+        ctx->relax_xcd = value ? 1 : 0;
     } else if (!strcmp(name, "relax3d.zchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "relax3d.zchunk must be >= 0 (0 = automatic)");
         ctx->relax_zchunk = value;

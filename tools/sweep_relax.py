@@ -29,23 +29,25 @@ def main():
     w = np.dtype(dtype).itemsize
     ctx = P.Context(0)
     n = args.n
-    cfgs = [("natural", 4, 0)]
+    cfgs = [("natural", 4, 0, 0)]
     if args.configs:
         for c in args.configs.split(","):
-            ty, zc = c.split(":")
-            cfgs.append(("xsplit", int(ty), int(zc)))
+            ty, zc, xcd = c.split(":")
+            cfgs.append(("xsplit", int(ty), int(zc), int(xcd)))
     else:
-        for ty in (1, 2, 4, 8):
-            for zc in (1, 8, 32, 64, 128, 0):
-                cfgs.append(("xsplit", ty, zc))
+        for xcd in (0, 1):
+            for ty in (2, 4, 8):
+                for zc in (1, 4, 8, 16, 32):
+                    cfgs.append(("xsplit", ty, zc, xcd))
     mgs = {lay: P.MultiGrid3D(ctx, [n] * 3, [0, 1, 0, 1, 0, 1], dtype, nlevels=1, layout=lay) for lay in ("natural", "xsplit")}
     e0, e1 = ctx.event(), ctx.event()
     times = {c: [] for c in cfgs}
     for r in range(args.rounds + 1):
         for c in cfgs:
-            lay, ty, zc = c
+            lay, ty, zc, xcd = c
             ctx.set_param("relax3d.ty", ty)
             ctx.set_param("relax3d.zchunk", zc)
+            ctx.set_param("relax3d.xcd", xcd)
             mg = mgs[lay]
             ctx.sync()
             ctx.record(e0)
@@ -60,7 +62,7 @@ def main():
         t = np.array(times[c])
         med, mn = float(np.median(t)), float(t.min())
         gbs = 3 * w * lups / (med * 1e-3) / 1e9
-        rows.append(dict(layout=c[0], ty=c[1], zchunk=c[2], ms_median=round(med, 4), ms_min=round(mn, 4),
+        rows.append(dict(layout=c[0], ty=c[1], zchunk=c[2], xcd=c[3], ms_median=round(med, 4), ms_min=round(mn, 4),
                          mlups=round(lups / (med * 1e-3) / 1e6, 1), alg_GBps=round(gbs, 1), frac_hbm=round(gbs / 8000.0, 4)))
     rows.sort(key=lambda r: r["ms_median"])
     for r in rows:
