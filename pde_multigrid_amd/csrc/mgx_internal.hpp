@@ -14,9 +14,10 @@ struct mgx_ctx {
     hipStream_t comm = nullptr;     // RCCL halo exchange / collectives
     hipEvent_t ev_compute = nullptr;  // compute -> comm ordering
     hipEvent_t ev_comm = nullptr;     // comm -> compute ordering
-    int relax_ty = 4;      // rows per block of relax3d_xs_kernel (tuning)
+    int relax_ty = 4;      // waves (row groups) per block of relax3d_xs_kernel (tuning)
     int relax_zchunk = 0;  // planes per z-chunk, 0 = automatic
     int relax_xcd = 1;     // XCD-aware block -> tile mapping
+    int relax_rows = 4;    // consecutive rows per lane (register blocking in y) of relax3d_xs_kernel
     void* scratch = nullptr;  // small device workspace (reductions, tables)
     size_t scratch_bytes = 0;
     void* rccl_comm = nullptr;  // ncclComm_t

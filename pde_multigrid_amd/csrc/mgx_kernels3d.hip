@@ -56,21 +56,22 @@ __global__ void __launch_bounds__(256) relax3d_colour_kernel(real* __restrict__ 
 }
 
 // ------------------------------------------------------------------ relax, one colour, XSplit
-// Thread (j, y) owns the x-pair {2j, 2j+1} of row y and marches through the planes
-// [z0, z1) of its z-chunk.  In plane z the point of `colour` in that pair is x = 2j + q,
-// q = (colour + y + z) & 1; it lives in half q of the row at index j.  Its six neighbours are
-// of the other colour (never written in this pass, so in-place is race-free):
-//   W, E : half 1-q of the same row, indices j-1+q and j+q (one of them is index j = "own")
-//   N, S : half q, index j, rows y-1 / y+1
-//   D, U : half q, index j, planes z-1 / z+1
-// and (half q, j, plane z+1) is exactly the "own" same-row value of step z+1, while
-// (half q, j, plane z-1) was the "own" value of step z-1: the column is carried in three
-// registers, so each step issues one streaming load of v (U), one of f, one store, and three
-// loads that hit in L1/L2 (the side neighbour and N/S were streamed in by adjacent threads one
-// step earlier).  vin and vout alias the same array; the entries read and the entries written
-// are disjoint by colour, which is what makes the __restrict__ qualification legitimate.
-template <class real, int TY>
-__global__ void __launch_bounds__(64 * TY)
+// Lane j of a wave owns the x-pair {2j, 2j+1} of R consecutive rows and marches through the planes
+// [z0, z1) of its z-chunk.  In plane z the point of `colour` in the pair of row y is x = 2j + q,
+// q = (colour + y + z) & 1; it lives in half q of the row at index j.  Its six neighbours are of the
+// other colour (never written in this pass, so updating in place is race-free):
+//   W, E : half 1-q of the same row, indices j-1+q and j+q; one of them is index j ("own"),
+//          the other ("side") belongs to the neighbouring lane
+//   N, S : half q, index j, rows y-1 / y+1  = the "own" values of the adjacent rows (q flips with y),
+//          so inside a thread's R rows they are registers; only the two outer rows are loaded
+//   D, U : half q, index j, planes z-1 / z+1 = the "own" values of the previous / next step
+//          (q flips with z): the column is carried in registers
+// Per step and thread: R streaming loads of v (U), R of f, R side loads and 2 edge-row loads that
+// hit in L1/L2, R stores.  All R rows' loads are issued before the first use, which keeps
+// R x 16 bytes of HBM traffic in flight per lane.  vin and vout alias the same array; the entries
+// read and the entries written are disjoint by colour, which is what makes __restrict__ legitimate.
+template <class real, int TYW, int R>
+__global__ void __launch_bounds__(64 * TYW)
     relax3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                       int sz, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy, int xcd_swizzle) {
     const int H = (sx + 1) >> 1;
@@ -85,30 +86,57 @@ __global__ void __launch_bounds__(64 * TY)
     }
     const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
     const int j = bx * 64 + threadIdx.x;
-    const int y = 1 + by * TY + threadIdx.y;
-    if (y >= sy - 1 || j >= H - 1) return;  // x = 2j+q <= sx-2 needs j <= H-2
+    // one wave per row group: y (hence the colour parity q and every row offset) is wave-uniform -> SGPRs
+    const int y0 = 1 + (by * TYW + __builtin_amdgcn_readfirstlane(threadIdx.y)) * R;
+    if (y0 >= sy - 1 || j >= H - 1) return;  // x = 2j+q <= sx-2 needs j <= H-2
+    const int nrows = min(R, sy - 1 - y0);    // rows y0 .. y0+nrows-1 are interior
     const int z0 = 1 + bz * zchunk;
     const int z1 = min(z0 + zchunk, sz - 1);
     if (z0 >= z1) return;
     const size_t sxy = (size_t)sx * sy;
-    size_t row = (size_t)y * sx + (size_t)z0 * sxy;  // base of row (y, z)
-    int q = (colour + y + z0) & 1;
-    real c_prev = vin[row - sxy + q * H + j];       // (half q(z0),   j, plane z0-1)
-    real c_cur = vin[row + (1 - q) * H + j];        // (half 1-q(z0), j, plane z0)
-#pragma unroll 2
+    // row bases at plane z0; rows past the last interior row are clamped onto it (loads stay valid,
+    // stores are suppressed)
+    size_t rowb[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) rowb[r] = (size_t)(y0 + (r < nrows ? r : nrows - 1)) * sx + (size_t)z0 * sxy;
+    int q = (colour + y0 + z0) & 1;  // parity of row r is q ^ (r & 1)
+    real c_prev[R], c_cur[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int qr = q ^ (r & 1);
+        c_prev[r] = vin[rowb[r] - sxy + qr * H + j];   // (half q_r,   j, plane z0-1)
+        c_cur[r] = vin[rowb[r] + (1 - qr) * H + j];    // (half 1-q_r, j, plane z0)
+    }
     for (int z = z0; z < z1; z++) {
-        const int hq = q * H, ho = (1 - q) * H;
-        const real c_next = vin[row + sxy + hq + j];  // U, and next step's own value
-        if (q | j) {                                  // x = 2j+q >= 1
-            const real side = q ? vin[row + ho + j + 1] : vin[row + ho + j - 1];
-            const real W = q ? c_cur : side;
-            const real E = q ? side : c_cur;
-            const real N = vin[row - sx + hq + j], S = vin[row + sx + hq + j];
-            vout[row + hq + j] = relax3d_point<real>(W, E, N, S, c_prev, c_next, f[row + hq + j], hx2, hy2, hz2);
+        real U[R], side[R], fv[R];
+        // lane j = 0 with q_r = 0 (x = 0, a boundary point that is never written) would read index -1:
+        // it reads index H-1 of half 0 instead and the result is discarded
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = q ^ (r & 1);
+            const int hq = qr * H, ho = (1 - qr) * H;
+            U[r] = vin[rowb[r] + sxy + hq + j];
+            side[r] = vin[rowb[r] + ho + j + (qr ? 1 : -1) + (qr | j ? 0 : H)];
+            fv[r] = f[rowb[r] + hq + j];
         }
-        c_prev = c_cur;
-        c_cur = c_next;
-        row += sxy;
+        const real Nedge = vin[rowb[0] - sx + q * H + j];
+        const real Sedge = vin[rowb[R - 1] + sx + (q ^ ((R - 1) & 1)) * H + j];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = q ^ (r & 1);
+            const real W = qr ? c_cur[r] : side[r];
+            const real E = qr ? side[r] : c_cur[r];
+            const real N = r == 0 ? Nedge : c_cur[r - 1];
+            const real S = r == R - 1 ? Sedge : c_cur[r + 1];
+            const real out = relax3d_point<real>(W, E, N, S, c_prev[r], U[r], fv[r], hx2, hy2, hz2);
+            if ((qr | j) && r < nrows) vout[rowb[r] + qr * H + j] = out;  // x = 2j+q_r >= 1
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            c_prev[r] = c_cur[r];
+            c_cur[r] = U[r];
+            rowb[r] += sxy;
+        }
         q ^= 1;
     }
 }
@@ -321,31 +349,44 @@ static int relax3d_natural(mgx_ctx* ctx, real* v, const real* f, const int n[3],
     return MGX_OK;
 }
 
-template <class real, int TY>
+template <class real, int TYW, int R>
 static void launch_xs(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int colour,
                       int zchunk) {
     const int H = (n[0] + 1) / 2;
-    const int gx = ceil_div(H - 1, 64), gy = ceil_div(n[1] - 2, TY), gz = ceil_div(n[2] - 2, zchunk);
-    hipLaunchKernelGGL((relax3d_xs_kernel<real, TY>), dim3((unsigned)gx * gy * gz), dim3(64, TY, 1), 0, ctx->compute,
+    const int gx = ceil_div(H - 1, 64), gy = ceil_div(n[1] - 2, TYW * R), gz = ceil_div(n[2] - 2, zchunk);
+    hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3((unsigned)gx * gy * gz), dim3(64, TYW, 1), 0, ctx->compute,
                        (const real*)v, v, f, n[0], n[1], n[2], hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
+}
+
+template <class real, int TYW>
+static void launch_xs_rows(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int colour,
+                           int zchunk, int rows) {
+    switch (rows) {
+        case 1: launch_xs<real, TYW, 1>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
+        case 2: launch_xs<real, TYW, 2>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
+        case 8: launch_xs<real, TYW, 8>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
+        default: launch_xs<real, TYW, 4>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
+    }
 }
 
 template <class real>
 static int relax3d_xsplit(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int ncycles) {
-    int ty = ctx->relax_ty, zchunk = ctx->relax_zchunk;
+    int ty = ctx->relax_ty, rows = ctx->relax_rows, zchunk = ctx->relax_zchunk;
+    while (rows > 1 && rows * ty > n[1] - 2) rows >>= 1;  // small levels: do not idle most of a block
+    while (ty > 1 && rows * ty > n[1] - 2) ty >>= 1;
     if (zchunk <= 0) {
         // enough z-chunks to give every CU several blocks; long enough chunks to amortise the 2-plane prologue
-        const long long tiles = (long long)ceil_div((n[0] + 1) / 2 - 1, 64) * ceil_div(n[1] - 2, ty);
-        zchunk = 64;
-        while (zchunk > 8 && tiles * ceil_div(n[2] - 2, zchunk) < 8LL * ctx->num_cus) zchunk >>= 1;
+        const long long tiles = (long long)ceil_div((n[0] + 1) / 2 - 1, 64) * ceil_div(n[1] - 2, ty * rows);
+        zchunk = 16;
+        while (zchunk > 2 && tiles * ceil_div(n[2] - 2, zchunk) < 8LL * ctx->num_cus) zchunk >>= 1;
     }
     for (int k = 0; k < ncycles; k++)
         for (int colour = 0; colour < 2; colour++) {
             switch (ty) {
-                case 1: launch_xs<real, 1>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
-                case 2: launch_xs<real, 2>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
-                case 8: launch_xs<real, 8>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
-                default: launch_xs<real, 4>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
+                case 1: launch_xs_rows<real, 1>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk, rows); break;
+                case 2: launch_xs_rows<real, 2>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk, rows); break;
+                case 8: launch_xs_rows<real, 8>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk, rows); break;
+                default: launch_xs_rows<real, 4>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk, rows); break;
             }
         }
     return MGX_OK;
@@ -563,8 +604,11 @@ MGX_DEFINE_MISC3D(f64, double)
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     MGX_REQUIRE(ctx && name, MGX_ERR_INVALID, "set_param: NULL argument");
     if (!strcmp(name, "relax3d.ty")) {
-        MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.ty must be 1, 2, 4 or 8");
+        MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.ty (waves per block) must be 1, 2, 4 or 8");
         ctx->relax_ty = value;
+    } else if (!strcmp(name, "relax3d.rows")) {
+        MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.rows must be 1, 2, 4 or 8");
+        ctx->relax_rows = value;
     } else if (!strcmp(name, "relax3d.xcd")) {
         ctx->relax_xcd = value ? 1 : 0;
     } else if (!strcmp(name, "relax3d.zchunk")) {

@@ -108,20 +108,25 @@ def test_3d_xsplit_pack_unpack(ctx):
             assert bits_equal(P.ops3d.unpack(ctx, P.xs_pack(a)), a)
 
 
-@pytest.mark.parametrize("ty,zchunk", [(1, 1), (2, 3), (4, 0), (8, 64), (4, 7)])
-def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, zchunk):
-    """rows per block / z-chunk length of the marching smoother are speed knobs only"""
+@pytest.mark.parametrize("ty,rows,zchunk", [(1, 1, 1), (2, 2, 3), (4, 4, 0), (8, 1, 64), (4, 8, 7), (1, 8, 2), (2, 4, 5)])
+def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, rows, zchunk):
+    """waves per block / rows per lane / z-chunk length of the marching smoother are speed knobs only"""
     n3, rg = (65, 33, 41), [-1, 1, 0, 2, 0.5, 3]
     rng = np.random.default_rng(5)
     v = rng.uniform(-1, 1, O.shape(n3))
     f = rng.uniform(-1, 1, O.shape(n3))
     ctx.set_param("relax3d.ty", ty)
+    ctx.set_param("relax3d.rows", rows)
     ctx.set_param("relax3d.zchunk", zchunk)
     try:
-        assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 3), O.relax3d(n3, rg, v, f, 3, dtype=np.float64))
+        for xcd in (0, 1):
+            ctx.set_param("relax3d.xcd", xcd)
+            assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 3), O.relax3d(n3, rg, v, f, 3, dtype=np.float64))
     finally:
         ctx.set_param("relax3d.ty", 4)
+        ctx.set_param("relax3d.rows", 4)
         ctx.set_param("relax3d.zchunk", 0)
+        ctx.set_param("relax3d.xcd", 1)
 
 
 def test_3d_size_violations_return_status(ctx):

@@ -29,23 +29,25 @@ def main():
     w = np.dtype(dtype).itemsize
     ctx = P.Context(0)
     n = args.n
-    cfgs = [("natural", 4, 0, 0)]
+    cfgs = [("natural", 4, 4, 0, 0)]
     if args.configs:
         for c in args.configs.split(","):
-            ty, zc, xcd = c.split(":")
-            cfgs.append(("xsplit", int(ty), int(zc), int(xcd)))
+            ty, rows, zc, xcd = c.split(":")
+            cfgs.append(("xsplit", int(ty), int(rows), int(zc), int(xcd)))
     else:
-        for xcd in (0, 1):
-            for ty in (2, 4, 8):
-                for zc in (1, 4, 8, 16, 32):
-                    cfgs.append(("xsplit", ty, zc, xcd))
+        for ty, rows in ((4, 1), (4, 2), (4, 4), (2, 4), (1, 4), (8, 4), (2, 8), (4, 8), (1, 8), (8, 2)):
+            for zc in (4, 8, 16, 32):
+                cfgs.append(("xsplit", ty, rows, zc, 1))
+        cfgs.append(("xsplit", 4, 4, 8, 0))
+        cfgs.append(("xsplit", 2, 4, 8, 0))
     mgs = {lay: P.MultiGrid3D(ctx, [n] * 3, [0, 1, 0, 1, 0, 1], dtype, nlevels=1, layout=lay) for lay in ("natural", "xsplit")}
     e0, e1 = ctx.event(), ctx.event()
     times = {c: [] for c in cfgs}
     for r in range(args.rounds + 1):
         for c in cfgs:
-            lay, ty, zc, xcd = c
+            lay, ty, rows, zc, xcd = c
             ctx.set_param("relax3d.ty", ty)
+            ctx.set_param("relax3d.rows", rows)
             ctx.set_param("relax3d.zchunk", zc)
             ctx.set_param("relax3d.xcd", xcd)
             mg = mgs[lay]
@@ -57,15 +59,15 @@ def main():
             if r > 0:
                 times[c].append(ms)
     lups = (n - 2) ** 3
-    rows = []
+    out = []
     for c in cfgs:
         t = np.array(times[c])
         med, mn = float(np.median(t)), float(t.min())
         gbs = 3 * w * lups / (med * 1e-3) / 1e9
-        rows.append(dict(layout=c[0], ty=c[1], zchunk=c[2], xcd=c[3], ms_median=round(med, 4), ms_min=round(mn, 4),
+        out.append(dict(layout=c[0], ty=c[1], rows=c[2], zchunk=c[3], xcd=c[4], ms_median=round(med, 4), ms_min=round(mn, 4),
                          mlups=round(lups / (med * 1e-3) / 1e6, 1), alg_GBps=round(gbs, 1), frac_hbm=round(gbs / 8000.0, 4)))
-    rows.sort(key=lambda r: r["ms_median"])
-    for r in rows:
+    out.sort(key=lambda r: r["ms_median"])
+    for r in out:
         print(json.dumps(r))
 
 
