@@ -17,7 +17,7 @@ struct mgx_ctx {
     int relax_ty = 4;      // waves (row groups) per block of relax3d_xs_kernel (tuning)
     int relax_zchunk = 0;  // planes per z-chunk, 0 = automatic
     int relax_xcd = 1;     // XCD-aware block -> tile mapping
-    int relax_rows = 4;    // consecutive rows per lane (register blocking in y) of relax3d_xs_kernel
+    int relax_rows = 2;    // consecutive rows per lane (register blocking in y) of relax3d_xs_kernel
     void* scratch = nullptr;  // small device workspace (reductions, tables)
     size_t scratch_bytes = 0;
     void* rccl_comm = nullptr;  // ncclComm_t

@@ -94,11 +94,12 @@ __global__ void __launch_bounds__(64 * TYW)
     const int z1 = min(z0 + zchunk, sz - 1);
     if (z0 >= z1) return;
     const size_t sxy = (size_t)sx * sy;
-    // row bases at plane z0; rows past the last interior row are clamped onto it (loads stay valid,
-    // stores are suppressed)
+    // row bases at plane z0.  Row y0+nrows may be the boundary row sy-1: it is loaded like any other row
+    // because its "own" value is the S neighbour of the last interior row; rows past sy-1 are clamped
+    // onto it (loads stay valid, nothing is stored for r >= nrows)
     size_t rowb[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) rowb[r] = (size_t)(y0 + (r < nrows ? r : nrows - 1)) * sx + (size_t)z0 * sxy;
+    for (int r = 0; r < R; r++) rowb[r] = (size_t)min(y0 + r, sy - 1) * sx + (size_t)z0 * sxy;
     int q = (colour + y0 + z0) & 1;  // parity of row r is q ^ (r & 1)
     real c_prev[R], c_cur[R];
 #pragma unroll
@@ -377,8 +378,8 @@ static int relax3d_xsplit(mgx_ctx* ctx, real* v, const real* f, const int n[3], 
     if (zchunk <= 0) {
         // enough z-chunks to give every CU several blocks; long enough chunks to amortise the 2-plane prologue
         const long long tiles = (long long)ceil_div((n[0] + 1) / 2 - 1, 64) * ceil_div(n[1] - 2, ty * rows);
-        zchunk = 16;
-        while (zchunk > 2 && tiles * ceil_div(n[2] - 2, zchunk) < 8LL * ctx->num_cus) zchunk >>= 1;
+        zchunk = 4;  // measured best at 513^3 (tools/sweep_relax.py): short chunks, many blocks
+        while (zchunk > 1 && tiles * ceil_div(n[2] - 2, zchunk) < 8LL * ctx->num_cus) zchunk >>= 1;
     }
     for (int k = 0; k < ncycles; k++)
         for (int colour = 0; colour < 2; colour++) {

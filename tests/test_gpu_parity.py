@@ -124,7 +124,7 @@ def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, rows, zchun
             assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 3), O.relax3d(n3, rg, v, f, 3, dtype=np.float64))
     finally:
         ctx.set_param("relax3d.ty", 4)
-        ctx.set_param("relax3d.rows", 4)
+        ctx.set_param("relax3d.rows", 2)
         ctx.set_param("relax3d.zchunk", 0)
         ctx.set_param("relax3d.xcd", 1)
 
