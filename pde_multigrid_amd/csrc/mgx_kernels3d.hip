@@ -73,18 +73,34 @@ __global__ void __launch_bounds__(256) relax3d_colour_kernel(real* __restrict__ 
 template <class real, int TYW, int R>
 __global__ void __launch_bounds__(64 * TYW)
     relax3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
-                      int sz, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy, int xcd_swizzle) {
+                      int sz, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy, int xcd_mode) {
     const int H = (sx + 1) >> 1;
     // 1-D grid decoded to (bx, by, bz).  Workgroups are dealt round-robin over the 8 XCDs
-    // (MI355X_MICROARCH.md: blocks b and b+8 share an XCD); with xcd_swizzle every XCD gets one
-    // contiguous run of tiles, so tiles adjacent in y / z (which re-read each other's edge rows and
-    // planes) share an L2.  Speed only: any mapping gives the same result.
+    // (MI355X_MICROARCH.md: blocks b and b+8 share an XCD, each XCD has its own 4 MiB L2).
+    //   xcd_mode 0: plain order, x fastest, then y tiles, then z-chunks
+    //   xcd_mode 1: every XCD gets one contiguous run of that order
+    //   xcd_mode 2: every XCD owns a contiguous set of xy tiles (a y-slab) and walks through its
+    //               z-chunks in order, so the two planes that consecutive z-chunks both read, and
+    //               the edge rows of y-adjacent tiles, are still in that XCD's L2 when re-read.
+    // Speed only: any mapping gives the same result (the grid holds 8*ceil(T/8)*gz blocks in mode 2).
     unsigned b = blockIdx.x;
-    if (xcd_swizzle) {
-        const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
-        b = k * per + (k < rem ? k : rem) + (b >> 3);
+    int bx, by, bz;
+    if (xcd_mode == 2) {
+        const unsigned T = gx * gy, Tx = (T + 7u) >> 3, k = b & 7u, i = b >> 3;
+        const unsigned tile = k * Tx + i % Tx;
+        if (tile >= T) return;
+        bz = i / Tx;
+        bx = tile % gx;
+        by = tile / gx;
+    } else {
+        if (xcd_mode == 1) {
+            const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
+            b = k * per + (k < rem ? k : rem) + (b >> 3);
+        }
+        bx = b % gx;
+        by = (b / gx) % gy;
+        bz = b / (gx * gy);
     }
-    const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
     const int j = bx * 64 + threadIdx.x;
     // one wave per row group: y (hence the colour parity q and every row offset) is wave-uniform -> SGPRs
     const int y0 = 1 + (by * TYW + __builtin_amdgcn_readfirstlane(threadIdx.y)) * R;
@@ -355,7 +371,8 @@ static void launch_xs(mgx_ctx* ctx, real* v, const real* f, const int n[3], real
                       int zchunk) {
     const int H = (n[0] + 1) / 2;
     const int gx = ceil_div(H - 1, 64), gy = ceil_div(n[1] - 2, TYW * R), gz = ceil_div(n[2] - 2, zchunk);
-    hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3((unsigned)gx * gy * gz), dim3(64, TYW, 1), 0, ctx->compute,
+    const unsigned nblocks = ctx->relax_xcd == 2 ? 8u * ((gx * gy + 7) / 8) * gz : (unsigned)gx * gy * gz;
+    hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
                        (const real*)v, v, f, n[0], n[1], n[2], hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
 }
 
@@ -611,7 +628,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.rows must be 1, 2, 4 or 8");
         ctx->relax_rows = value;
     } else if (!strcmp(name, "relax3d.xcd")) {
-        ctx->relax_xcd = value ? 1 : 0;
+        MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "relax3d.xcd must be 0, 1 or 2");
+        ctx->relax_xcd = value;
     } else if (!strcmp(name, "relax3d.zchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "relax3d.zchunk must be >= 0 (0 = automatic)");
         ctx->relax_zchunk = value;

@@ -119,7 +119,7 @@ def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, rows, zchun
     ctx.set_param("relax3d.rows", rows)
     ctx.set_param("relax3d.zchunk", zchunk)
     try:
-        for xcd in (0, 1):
+        for xcd in (0, 1, 2):
             ctx.set_param("relax3d.xcd", xcd)
             assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 3), O.relax3d(n3, rg, v, f, 3, dtype=np.float64))
     finally:

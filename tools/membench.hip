@@ -43,6 +43,24 @@ __global__ void write8(double* __restrict__ a, size_t n) {
     if (i < n) a[i] = 1.0;
 }
 
+// the x-split smoother's pattern: array a is made of rows of ROW doubles; even rows are read, odd rows are
+// written (same array, reads and writes interleaved at ROW*8 bytes), b is a second read stream
+__global__ void interleaved_rw(double* __restrict__ a, const double* __restrict__ b, size_t nrows, int ROW) {
+    size_t r = blockIdx.x;
+    for (int j = threadIdx.x; j < ROW; j += blockDim.x) {
+        double x = a[(2 * r) * (size_t)ROW + j], y = b[r * (size_t)ROW + j];
+        a[(2 * r + 1) * (size_t)ROW + j] = x + 3.0 * y;
+    }
+}
+// same traffic with the written rows in a separate array c
+__global__ void separate_rw(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ c, size_t nrows, int ROW) {
+    size_t r = blockIdx.x;
+    for (int j = threadIdx.x; j < ROW; j += blockDim.x) {
+        double x = a[r * (size_t)ROW + j], y = b[r * (size_t)ROW + j];
+        c[r * (size_t)ROW + j] = x + 3.0 * y;
+    }
+}
+
 template <class F> double timeit(F f, int reps = 10) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     f(); CK(hipDeviceSynchronize());
@@ -72,5 +90,12 @@ int main(int argc, char** argv) {
     s = timeit([&] { write8<<<g(n), B>>>(a, n); });                        printf("write  8B/lane            : %8.1f GB/s\n", 1.0 * n * 8 / s / 1e9);
     // misaligned (offset by one double) 16B/lane copy: what unpadded odd-length rows cost
     s = timeit([&] { copy_k<double2><<<g(n / 2 - 1), B>>>((double2*)(a + 1), (double2*)(b + 1), n / 2 - 1); }); printf("copy  16B/lane misaligned : %8.1f GB/s\n", 2.0 * n * 8 / s / 1e9);
+    for (int ROW : {256, 257, 1024, 4096}) {
+        size_t nrows = n / 2 / ROW;  // a holds 2*nrows rows
+        s = timeit([&] { interleaved_rw<<<(unsigned)nrows, 256>>>(a, b, nrows, ROW); });
+        printf("rows of %4d: read/write interleaved in one array: %8.1f GB/s", ROW, 3.0 * nrows * ROW * 8 / s / 1e9);
+        s = timeit([&] { separate_rw<<<(unsigned)nrows, 256>>>(a, b, c, nrows, ROW); });
+        printf("   separate arrays: %8.1f GB/s\n", 3.0 * nrows * ROW * 8 / s / 1e9);
+    }
     return 0;
 }

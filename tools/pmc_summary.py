@@ -35,7 +35,8 @@ def main():
                 counters[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for path in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(path)):
-                key = (r["Kernel_Name"], int(r["Grid_Size"]))
+                grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+                key = (r["Kernel_Name"], grid)
                 durations[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     if stats_rows:
         with open(args.out + "_kernel_stats.csv", "w") as fh:

@@ -35,11 +35,10 @@ def main():
             ty, rows, zc, xcd = c.split(":")
             cfgs.append(("xsplit", int(ty), int(rows), int(zc), int(xcd)))
     else:
-        for ty, rows in ((4, 1), (4, 2), (4, 4), (2, 4), (1, 4), (8, 4), (2, 8), (4, 8), (1, 8), (8, 2)):
-            for zc in (4, 8, 16, 32):
-                cfgs.append(("xsplit", ty, rows, zc, 1))
-        cfgs.append(("xsplit", 4, 4, 8, 0))
-        cfgs.append(("xsplit", 2, 4, 8, 0))
+        for xcd in (2, 1):
+            for ty, rows in ((4, 2), (4, 1), (2, 4), (4, 4), (8, 2), (8, 1), (2, 2)):
+                for zc in (2, 4, 8, 16, 32):
+                    cfgs.append(("xsplit", ty, rows, zc, xcd))
     mgs = {lay: P.MultiGrid3D(ctx, [n] * 3, [0, 1, 0, 1, 0, 1], dtype, nlevels=1, layout=lay) for lay in ("natural", "xsplit")}
     e0, e1 = ctx.event(), ctx.event()
     times = {c: [] for c in cfgs}
