@@ -222,6 +222,45 @@ __global__ void __launch_bounds__(256) interpolate3d_kernel(real* __restrict__ f
     else fine[fi] = e;
 }
 
+// XSplit form: one thread per coarse cell (i, py, pz) produces the 2 x 2 x 2 fine points
+// (2i | 2i+1, 2py | 2py+1, 2pz | 2pz+1) from the 8 coarse values c[i..i+1][py..py+1][pz..pz+1] it loads once.
+// Fine accesses are contiguous per half-row (lane i -> even half index i and odd half index i); the
+// parity class of every point is a compile-time constant after unrolling, so there is no divergence.
+template <class real, bool ADD>
+__global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict__ fine, int fx, int fy, int fz,
+                                                               const real* __restrict__ coarse, int cx, int cy) {
+    const int FH = (fx + 1) >> 1, CH = (cx + 1) >> 1;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int py = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pz = blockIdx.z;
+    if (i >= FH - 1 || py >= cy - 1) return;  // fine x = 2i+1 <= fx-2, fine y = 2py+1 <= fy-2
+    const size_t cxy = (size_t)cx * cy, fxy = (size_t)fx * fy;
+    real c[2][2][2];
+#pragma unroll
+    for (int dz = 0; dz < 2; dz++)
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++)
+                c[dx][dy][dz] = coarse[XSplit::pos(i + dx, CH) + (size_t)(py + dy) * cx + (size_t)(pz + dz) * cxy];
+    auto get = [&](int dx, int dy, int dz) { return c[dx][dy][dz]; };
+#pragma unroll
+    for (int dz = 0; dz < 2; dz++) {
+        const int z = 2 * pz + dz;
+        if (z < 1) continue;
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++) {
+            const int y = 2 * py + dy;
+            if (y < 1) continue;
+            const size_t row = (size_t)y * fx + (size_t)z * fxy;
+            const real e0 = interpolate3d_point<real>(0, dy, dz, get);
+            const real e1 = interpolate3d_point<real>(1, dy, dz, get);
+            if (i >= 1) fine[row + i] = ADD ? fine[row + i] + e0 : e0;   // x = 2i
+            fine[row + FH + i] = ADD ? fine[row + FH + i] + e1 : e1;     // x = 2i+1
+        }
+    }
+}
+
 template <class real, class L>
 __global__ void __launch_bounds__(256) correct3d_kernel(real* __restrict__ fine, const real* __restrict__ err, int sx,
                                                         int sy, int sz) {
@@ -268,54 +307,63 @@ __global__ void __launch_bounds__(256) relayout3d_kernel(const real* __restrict_
 }
 
 // ------------------------------------------------------------------ residual + restrict fused
-// One block produces a CTX x CTY tile of one coarse plane.  It evaluates the fine
-// residual on the (2*CTX+1) x (2*CTY+1) x 3 fine points the tile's 27-point stencils touch,
-// plane by plane into LDS (boundary points -> 0 exactly like CalculateResidual), then
-// applies the full-weighting formula.  The fine residual never goes to HBM.
+// One block produces a CTX x CTY tile of coarse points for a chunk of coarse planes [pz0, pz1) and
+// marches through them.  The fine residual lives only in an LDS ring of 4 planes of the
+// (2*CTX+1) x (2*CTY+1) fine window the tile's 27-point stencils touch: every step adds the two new
+// fine planes 2pz, 2pz+1 (plane 2pz-1 is the previous step's 2(pz-1)+1), boundary points -> 0 exactly
+// like CalculateResidual, then applies the full-weighting formula.  The fine residual never goes to
+// HBM and each fine plane's residual is evaluated once per tile (plus the one-point window overlap).
 template <class real, class L, int MODE, int CTX, int CTY>
 __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __restrict__ v, const real* __restrict__ f,
                                                                   int sx, int sy, int sz, real hx2, real hy2, real hz2,
-                                                                  real* __restrict__ coarse, int cx, int cy, int cz) {
+                                                                  real* __restrict__ coarse, int cx, int cy, int cz,
+                                                                  int pzchunk) {
     constexpr int FX = 2 * CTX + 1, FY = 2 * CTY + 1;
-    __shared__ real res[3][FY][FX + 1];
-    const int pz = blockIdx.z;
+    __shared__ real res[4][FY][FX + 1];
+    const int pz0 = blockIdx.z * pzchunk, pz1 = min(pz0 + pzchunk, cz);
     const int px0 = blockIdx.x * CTX, py0 = blockIdx.y * CTY;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     const int nthreads = blockDim.x * blockDim.y;
     const int H = (sx + 1) >> 1, CH = (cx + 1) >> 1;
     const size_t sxy = (size_t)sx * sy;
-    const bool zinterior = pz > 0 && pz < cz - 1;
     // fine window origin (may be -1 at the low edge: those entries are never read)
     const int gx0 = 2 * px0 - 1, gy0 = 2 * py0 - 1;
-    if (zinterior) {
-        for (int k = 0; k < 3; k++) {
-            const int gz = 2 * pz - 1 + k;  // 1 .. sz-2 for interior coarse planes
-            for (int t = tid; t < FX * FY; t += nthreads) {
-                const int ly = t / FX, lx = t - ly * FX;
-                const int gx = gx0 + lx, gy = gy0 + ly;
-                real rv = (real)0;
-                if (gx >= 1 && gx < sx - 1 && gy >= 1 && gy < sy - 1) {
-                    const size_t row = (size_t)gy * sx + (size_t)gz * sxy;
-                    const size_t i = row + L::pos(gx, H);
-                    rv = residual3d_point<real, MODE>(v[row + L::pos(gx - 1, H)], v[row + L::pos(gx + 1, H)], v[i - sx],
-                                                      v[i + sx], v[i - sxy], v[i + sxy], v[i], f[i], hx2, hy2, hz2);
-                }
-                res[k][ly][lx] = rv;
+    auto fill = [&](int gz) {  // residual of fine plane gz into ring slot gz & 3
+        const bool zin = gz >= 1 && gz < sz - 1;
+        for (int t = tid; t < FX * FY; t += nthreads) {
+            const int ly = t / FX, lx = t - ly * FX;
+            const int gx = gx0 + lx, gy = gy0 + ly;
+            real rv = (real)0;
+            if (zin && gx >= 1 && gx < sx - 1 && gy >= 1 && gy < sy - 1) {
+                const size_t row = (size_t)gy * sx + (size_t)gz * sxy;
+                const size_t i = row + L::pos(gx, H);
+                rv = residual3d_point<real, MODE>(v[row + L::pos(gx - 1, H)], v[row + L::pos(gx + 1, H)], v[i - sx],
+                                                  v[i + sx], v[i - sxy], v[i + sxy], v[i], f[i], hx2, hy2, hz2);
             }
+            res[gz & 3][ly][lx] = rv;
         }
-    }
-    __syncthreads();
-    for (int t = tid; t < CTX * CTY; t += nthreads) {
-        const int ty = t / CTX, tx = t - ty * CTX;
-        const int px = px0 + tx, py = py0 + ty;
-        if (px >= cx || py >= cy) continue;
-        const size_t ci = L::pos(px, CH) + (size_t)py * cx + (size_t)pz * cx * cy;
-        if (px == 0 || px == cx - 1 || py == 0 || py == cy - 1 || !zinterior) {
-            coarse[ci] = (real)0;  // injection of a boundary residual, which is 0 (:704-705 then :113-119)
-            continue;
+    };
+    if (pz0 > 0) fill(2 * pz0 - 1);
+    for (int pz = pz0; pz < pz1; pz++) {
+        const bool zinterior = pz > 0 && pz < cz - 1;
+        if (pz < cz - 1) {  // planes 2pz and 2pz+1 exist
+            fill(2 * pz);
+            fill(2 * pz + 1);
         }
-        const int lx = 2 * tx + 1, ly = 2 * ty + 1;
-        coarse[ci] = restrict3d_point<real>([&](int dx, int dy, int dz) { return res[1 + dz][ly + dy][lx + dx]; });
+        __syncthreads();
+        for (int t = tid; t < CTX * CTY; t += nthreads) {
+            const int ty = t / CTX, tx = t - ty * CTX;
+            const int px = px0 + tx, py = py0 + ty;
+            if (px >= cx || py >= cy) continue;
+            const size_t ci = L::pos(px, CH) + (size_t)py * cx + (size_t)pz * cx * cy;
+            if (px == 0 || px == cx - 1 || py == 0 || py == cy - 1 || !zinterior) {
+                coarse[ci] = (real)0;  // injection of a boundary residual, which is 0 (:704-705 then :113-119)
+                continue;
+            }
+            const int lx = 2 * tx + 1, ly = 2 * ty + 1, g = 2 * pz;
+            coarse[ci] = restrict3d_point<real>([&](int dx, int dy, int dz) { return res[(g + dz) & 3][ly + dy][lx + dx]; });
+        }
+        __syncthreads();  // slot (2pz-1)&3 is overwritten by the next step's plane 2pz+3
     }
 }
 
@@ -461,8 +509,12 @@ int interpolate3d(mgx_ctx* ctx, real* fine, const int fn[3], const real* coarse,
     if (st) return st;
     st = check_coarse3(fn, cn, "interpolate3d");
     if (st) return st;
-    hipLaunchKernelGGL((interpolate3d_kernel<real, L, ADD>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute,
-                       fine, fn[0], fn[1], fn[2], coarse, cn[0], cn[1]);
+    if (L::xsplit)
+        hipLaunchKernelGGL((interpolate3d_xs_kernel<real, ADD>), grd((fn[0] + 1) / 2 - 1, cn[1] - 1, cn[2] - 1), blk(), 0,
+                           ctx->compute, fine, fn[0], fn[1], fn[2], coarse, cn[0], cn[1]);
+    else
+        hipLaunchKernelGGL((interpolate3d_kernel<real, L, ADD>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute,
+                           fine, fn[0], fn[1], fn[2], coarse, cn[0], cn[1]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -504,13 +556,16 @@ int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[
                 "residual_restrict3d: bad mode %d", mode);
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
     constexpr int CTX = 32, CTY = 8;
-    dim3 g(ceil_div(cn[0], CTX), ceil_div(cn[1], CTY), cn[2]);
+    const int tiles = ceil_div(cn[0], CTX) * ceil_div(cn[1], CTY);
+    int pzchunk = ctx->rr_pzchunk > 0 ? ctx->rr_pzchunk : 8;  // coarse planes per block (1 extra fine plane per chunk)
+    while (pzchunk > 1 && (long long)tiles * ceil_div(cn[2], pzchunk) < 4LL * ctx->num_cus) pzchunk >>= 1;
+    dim3 g(ceil_div(cn[0], CTX), ceil_div(cn[1], CTY), ceil_div(cn[2], pzchunk));
     if (mode == MGX_RESIDUAL_REF_COMPAT)
         hipLaunchKernelGGL((residual_restrict3d_kernel<real, L, 0, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1],
-                           n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2]);
+                           n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk);
     else
         hipLaunchKernelGGL((residual_restrict3d_kernel<real, L, 1, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1],
-                           n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2]);
+                           n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -630,6 +685,9 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "relax3d.xcd")) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "relax3d.xcd must be 0, 1 or 2");
         ctx->relax_xcd = value;
+    } else if (!strcmp(name, "residual_restrict3d.pzchunk")) {
+        MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "residual_restrict3d.pzchunk must be >= 0 (0 = automatic)");
+        ctx->rr_pzchunk = value;
     } else if (!strcmp(name, "relax3d.zchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "relax3d.zchunk must be >= 0 (0 = automatic)");
         ctx->relax_zchunk = value;
