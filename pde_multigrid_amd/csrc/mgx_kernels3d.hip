@@ -328,19 +328,41 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
     const size_t sxy = (size_t)sx * sy;
     // fine window origin (may be -1 at the low edge: those entries are never read)
     const int gx0 = 2 * px0 - 1, gy0 = 2 * py0 - 1;
-    auto fill = [&](int gz) {  // residual of fine plane gz into ring slot gz & 3
+    // residual of fine plane gz into ring slot gz & 3.  The window is walked with a compile-time trip
+    // count and all global loads of a thread's points are issued before the first division, so one
+    // thread keeps NPT x 8 loads in flight instead of 8.
+    constexpr int NPT = (FX * FY + 255) / 256;
+    auto fill = [&](int gz) {
         const bool zin = gz >= 1 && gz < sz - 1;
-        for (int t = tid; t < FX * FY; t += nthreads) {
+        real O[NPT], E[NPT], N[NPT], S[NPT], D[NPT], U[NPT], C[NPT], F[NPT];
+        bool in[NPT];
+#pragma unroll
+        for (int k = 0; k < NPT; k++) {
+            const int t = tid + k * 256;
             const int ly = t / FX, lx = t - ly * FX;
             const int gx = gx0 + lx, gy = gy0 + ly;
-            real rv = (real)0;
-            if (zin && gx >= 1 && gx < sx - 1 && gy >= 1 && gy < sy - 1) {
+            in[k] = zin && t < FX * FY && gx >= 1 && gx < sx - 1 && gy >= 1 && gy < sy - 1;
+            if (in[k]) {
                 const size_t row = (size_t)gy * sx + (size_t)gz * sxy;
                 const size_t i = row + L::pos(gx, H);
-                rv = residual3d_point<real, MODE>(v[row + L::pos(gx - 1, H)], v[row + L::pos(gx + 1, H)], v[i - sx],
-                                                  v[i + sx], v[i - sxy], v[i + sxy], v[i], f[i], hx2, hy2, hz2);
+                O[k] = v[row + L::pos(gx - 1, H)];
+                E[k] = v[row + L::pos(gx + 1, H)];
+                N[k] = v[i - sx];
+                S[k] = v[i + sx];
+                D[k] = v[i - sxy];
+                U[k] = v[i + sxy];
+                C[k] = v[i];
+                F[k] = f[i];
             }
-            res[gz & 3][ly][lx] = rv;
+        }
+#pragma unroll
+        for (int k = 0; k < NPT; k++) {
+            const int t = tid + k * 256;
+            if (t < FX * FY) {
+                const int ly = t / FX, lx = t - ly * FX;
+                res[gz & 3][ly][lx] =
+                    in[k] ? residual3d_point<real, MODE>(O[k], E[k], N[k], S[k], D[k], U[k], C[k], F[k], hx2, hy2, hz2) : (real)0;
+            }
         }
     };
     if (pz0 > 0) fill(2 * pz0 - 1);
