@@ -37,6 +37,19 @@
 extern "C" {
 #endif
 
+/* Which planes of a level one rank of a z-slab decomposition holds (global plane indices).  Pure host
+ * arithmetic; also used by the CPU emulation test of the decomposition. */
+typedef struct mgSlabPlan {
+    int zlo, zhi;   /* owned planes [zlo, zhi); the last rank also owns the boundary plane sizeZ-1 */
+    int glo, ghi;   /* ghost planes below (2 on ranks > 0) and above (1 on ranks < P-1) */
+    int zoff, nzl;  /* local array = global planes [zoff, zoff + nzl), zoff = zlo - glo */
+    int ubeg, uend; /* planes the smoother updates: owned and interior, [max(zlo,1), min(zhi, sizeZ-1)) */
+} mgSlabPlan;
+/* number of leading levels that stay distributed: every rank owns an even number >= min_planes of planes */
+int mg_dist_num_levels(int sizeZ_finest, int nranks, int numGrids, int min_planes);
+int mg_dist_num_levels_single(int sizeZ_finest, int numGrids, int min_planes);
+int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
+
 #define MG_DECLARE(R, real)                                                                              \
     /* ------------------------------------------------------------------ 3D ------ */                  \
     typedef struct mgGrid3D_##R {                                                                        \
@@ -93,6 +106,35 @@ extern "C" {
     int mg3d_solve_##R(mgx_ctx* ctx, real* grid, const real* rhs, const int sizeXYZ[3],                  \
                        const real range[6], int nlevels, int fmg, int v0, int v1, int v2, int ncycles,   \
                        int residual_mode);                                                               \
+    /* ---- z-slab decomposed 3D V-cycle (one process per GPU; csrc/host/mg_dist3d.inc) ---- */         \
+    typedef struct mgSlab3D_##R {                                                                        \
+        real* d_v; /* local planes [zoff, zoff+nzl) of the level, x-split layout, ghosts included */     \
+        real* d_f;                                                                                       \
+        int sizeXYZ[3]; /* GLOBAL sizes of the level */                                                  \
+        mgSlabPlan plan;                                                                                 \
+        real h_x, h_y, h_z;                                                                              \
+        real x_a, y_a, z_a;                                                                              \
+    } mgSlab3D_##R;                                                                                      \
+    typedef struct mgDistMultiGrid3D_##R {                                                               \
+        mgSlab3D_##R** slabs;      /* levels 0 .. numDist-1 */                                           \
+        int numDist;               /* number of distributed levels (mg_dist_num_levels) */               \
+        int numGrids;              /* total levels of the cycle, public and mutable like the reference */\
+        int maxGrids;                                                                                    \
+        mgMultiGrid3D_##R* tail;   /* replicated hierarchy for levels >= numDist */                      \
+        mgx_ctx* ctx;                                                                                    \
+        int rank, nranks;                                                                                \
+        int residual_mode;                                                                               \
+        real* d_share;             /* staging for the agglomeration all-gather */                        \
+    } mgDistMultiGrid3D_##R;                                                                             \
+    int mgDistMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6], \
+                                       int min_planes, mgDistMultiGrid3D_##R** out);                     \
+    void mgDistMultiGrid3D_##R##_destroy(mgDistMultiGrid3D_##R* mg);                                     \
+    int mgDistMultiGrid3D_##R##_InitF(mgDistMultiGrid3D_##R* mg, int gridID);                            \
+    int mgDistMultiGrid3D_##R##_Relax(mgDistMultiGrid3D_##R* mg, int gridID, int ncycles);               \
+    int mgDistMultiGrid3D_##R##_VCycle(mgDistMultiGrid3D_##R* mg, int gridID, int v1, int v2);           \
+    int mgDistMultiGrid3D_##R##_upload_v(mgDistMultiGrid3D_##R* mg, int gridID, const real* host_full);  \
+    int mgDistMultiGrid3D_##R##_upload_f(mgDistMultiGrid3D_##R* mg, int gridID, const real* host_full);  \
+    int mgDistMultiGrid3D_##R##_download_v(mgDistMultiGrid3D_##R* mg, int gridID, real* host_full);      \
     /* ------------------------------------------------------------------ 2D ------ */                  \
     typedef struct mgGrid2D_##R {                                                                        \
         real* h_v;                                                                                       \

@@ -161,6 +161,21 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                                           const int cn[3]);                                             \
     int mgx3dxs_init_f_##SFX(mgx_ctx* ctx, real* f, const int n[3], double c, const double* host_tx,    \
                              const double* host_ty, const double* host_tz);                             \
+    /* z-slab forms for the multi-GPU decomposition.  A slab is a local x-split array of consecutive */ \
+    /* z-planes of a level whose GLOBAL sizes are n[] (cn[] for the coarse level); it starts at       */ \
+    /* global plane zoff.  relax_colour_slab: ONE colour pass (colour 0 = red: (x+y+z_global) even)   */ \
+    /* over the local planes [zbeg, zend); the planes next to that range are read as ghosts.          */ \
+    /* residual_restrict_slab / interpolate_correct_slab: global coarse planes [pzbeg, pzend);        */ \
+    /* interpolate_correct writes the fine planes 2pz and 2pz+1 of every listed pz (z = 0 skipped).   */ \
+    int mgx3dxs_relax_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy,           \
+                                        const real h[3], int colour, int zbeg, int zend, int zoff);     \
+    int mgx3dxs_residual_restrict_slab_##SFX(mgx_ctx* ctx, const real* v, const real* f,                \
+                                             const int n[3], int fzoff, const real h[3], int mode,      \
+                                             real* coarse_f, const int cn[3], int czoff, int pzbeg,     \
+                                             int pzend);                                                \
+    int mgx3dxs_interpolate_correct_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff,        \
+                                               const real* coarse_v, const int cn[3], int czoff,        \
+                                               int pzbeg, int pzend);                                   \
     int mgx2d_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[2], const real h[2],        \
                           const real a[2], const real A[4], int alfa, int ncycles);                     \
     int mgx2d_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[2],       \
@@ -189,14 +204,21 @@ int mgx_comm_unique_id(void* host_id_bytes);
 int mgx_comm_init(mgx_ctx* ctx, const void* host_id_bytes, int rank, int nranks);
 int mgx_comm_destroy(mgx_ctx* ctx);
 int mgx_comm_rank(const mgx_ctx* ctx, int* rank, int* nranks);
-/* Exchange ghost planes with the z-neighbours on a non-periodic chain: send `count`
- * reals from send_down to rank-1 and from send_up to rank+1, receive into recv_down
- * (from rank-1) and recv_up (from rank+1).  Pointers towards a missing neighbour are
- * ignored.  elem_bytes = 4 or 8.  Asynchronous on the comm stream: it first waits for
- * everything enqueued so far on the compute stream; mgx_comm_wait makes the compute
- * stream wait for the exchange. */
-int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_down, void* recv_down, const void* send_up,
-                           void* recv_up, size_t count, int elem_bytes);
+/* Test transport: `nranks` host threads of one process, one context each, all on the same device;
+ * device-to-device copies and a pthread barrier stand in for RCCL so that the slab-decomposed cycle
+ * can be verified on a single-GPU box.  Every rank's thread must take part in every exchange. */
+typedef struct mgx_local_group mgx_local_group;
+int mgx_local_group_create(int nranks, mgx_local_group** out);
+int mgx_local_group_destroy(mgx_local_group* group);
+int mgx_comm_init_local(mgx_ctx* ctx, mgx_local_group* group, int rank);
+/* Exchange ghost planes with the z-neighbours on a non-periodic chain of ranks (rank-1 = "lower",
+ * rank+1 = "upper").  Counts are in elements of elem_bytes (4 or 8) and must match what the
+ * neighbour passes for the opposite direction.  Buffers towards a missing neighbour are ignored.
+ * Asynchronous on the comm stream: it first waits for everything enqueued so far on the compute
+ * stream; mgx_comm_wait makes the compute stream wait for the exchange. */
+int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_to_lower, size_t count_to_lower, void* recv_from_lower,
+                           size_t count_from_lower, const void* send_to_upper, size_t count_to_upper,
+                           void* recv_from_upper, size_t count_from_upper, int elem_bytes);
 int mgx_comm_wait(mgx_ctx* ctx);
 /* all-gather `count` reals per rank (agglomeration of a coarse level) and all-reduce one
  * double (residual norm).  Both enqueue on the comm stream with the same ordering rules. */

@@ -81,6 +81,11 @@ void cycle1(int n, const real range[2], int nlevels, int mode, int v0, int v1, i
         geom3<real>(n, range, h, a);                                                                    \
         relax3<real>(v, f, n, h, ncycles);                                                              \
     }                                                                                                   \
+    void mgo3d_relax_colour_##SFX(const int n[3], const real range[6], real* v, const real* f, int colour) { \
+        real h[3], a[3];                                                                                \
+        geom3<real>(n, range, h, a);                                                                    \
+        relax3_colour<real>(v, f, n, h, colour);                                                        \
+    }                                                                                                   \
     void mgo3d_residual_##SFX(const int n[3], const real range[6], const real* v, const real* f,        \
                               real* r, int mode) {                                                      \
         real h[3], a[3];                                                                                \

@@ -110,6 +110,27 @@ void relax3(real* v, const real* f, const int n[3], const real h[3], int ncycles
     }
 }
 
+// One colour pass of Relax (colour 0 = red: (x+y+z) even, :515; 1 = black, :544) -- the unit between
+// two ghost-plane exchanges of the z-slab decomposition (test emulation of the multi-GPU schedule).
+template <class real>
+void relax3_colour(real* v, const real* f, const int n[3], const real h[3], int colour) {
+    const int sx = n[0], sy = n[1], sz = n[2];
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    const size_t sxy = (size_t)sx * sy;
+    for (int y = 1; y < sy - 1; y++)
+        for (int x = 1; x < sx - 1; x++)
+            for (int z = 1; z < sz - 1; z++) {
+                if (((y + x + z) % 2 == 0) != (colour == 0)) continue;
+                const size_t i = x + (size_t)y * sx + (size_t)z * sxy;
+                const real O = v[i - 1], E = v[i + 1];
+                const real N = v[i - sx], S = v[i + sx];
+                const real D = v[i - sxy], U = v[i + sxy];
+                v[i] = (O * (hy2 * hz2) + E * (hy2 * hz2) + N * (hx2 * hz2) + S * (hx2 * hz2) + D * (hx2 * hy2) + U * (hx2 * hy2) -
+                        f[i] * hx2 * hy2 * hz2) /
+                       (2 * (hy2 * hz2 + hx2 * hz2 + hx2 * hy2));
+            }
+}
+
 // CalculateResidual.  REF_COMPAT keeps the reference's sign quirk (-S, -U);
 // CORRECT uses +S, +U.                                   N3/MultiGrid3D.cpp:678-730 (:723)
 template <class real>

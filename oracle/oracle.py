@@ -111,6 +111,15 @@ def relax3d(n, rng, v, f, ncycles, dtype=np.float32):
     return v
 
 
+def relax_colour3d(n, rng, v, f, colour, dtype=np.float32):
+    """one colour pass (0 = red, 1 = black) over all interior points"""
+    fn, ct = _fn("mgo3d_relax_colour", dtype)
+    v = _arr(v, dtype).copy()
+    f = _arr(f, dtype)
+    fn(_ip(n), _rp(rng, ct), _p(v), _p(f), C.c_int(colour))
+    return v
+
+
 def residual3d(n, rng, v, f, mode=REF_COMPAT, dtype=np.float32):
     fn, ct = _fn("mgo3d_residual", dtype)
     v = _arr(v, dtype)

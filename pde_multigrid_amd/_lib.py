@@ -3,6 +3,11 @@
 The product path has NO CPU fallback for the 2D/3D operators: if the library is missing this
 module raises ImportError, and every call that needs a device returns MGX_ERR_NOGPU
 (raised as MgxError) when no MI355X is visible.
+
+Load order: PyTorch-ROCm bundles its own copies of libamdhip64 / librccl (same sonames as /opt/rocm's).
+A process that uses both must import torch BEFORE this module, so that libmgx binds to the copies torch
+loaded; the opposite order mixes two ROCm runtimes and aborts at exit.  bench.py (N > 1) and the gloo
+test workers do that; everything else never imports torch.
 """
 import ctypes as C
 import os

@@ -22,6 +22,7 @@ struct mgx_ctx {
     void* scratch = nullptr;  // small device workspace (reductions, tables)
     size_t scratch_bytes = 0;
     void* rccl_comm = nullptr;  // ncclComm_t
+    void* local_group = nullptr;  // mgx_local_group* (in-process test transport)
     int rank = 0, nranks = 1;
     int num_cus = 256;
 };

@@ -73,7 +73,8 @@ __global__ void __launch_bounds__(256) relax3d_colour_kernel(real* __restrict__ 
 template <class real, int TYW, int R>
 __global__ void __launch_bounds__(64 * TYW)
     relax3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
-                      int sz, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy, int xcd_mode) {
+                      int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
+                      int xcd_mode) {
     const int H = (sx + 1) >> 1;
     // 1-D grid decoded to (bx, by, bz).  Workgroups are dealt round-robin over the 8 XCDs
     // (MI355X_MICROARCH.md: blocks b and b+8 share an XCD, each XCD has its own 4 MiB L2).
@@ -106,8 +107,11 @@ __global__ void __launch_bounds__(64 * TYW)
     const int y0 = 1 + (by * TYW + __builtin_amdgcn_readfirstlane(threadIdx.y)) * R;
     if (y0 >= sy - 1 || j >= H - 1) return;  // x = 2j+q <= sx-2 needs j <= H-2
     const int nrows = min(R, sy - 1 - y0);    // rows y0 .. y0+nrows-1 are interior
-    const int z0 = 1 + bz * zchunk;
-    const int z1 = min(z0 + zchunk, sz - 1);
+    // planes [zbeg, zend) of the local array are updated (1 .. sz-2 for a whole grid; the owned planes of
+    // a z-slab, whose neighbours below / above are ghost planes); `colour` already includes the parity of
+    // the slab's global z offset
+    const int z0 = zbeg + bz * zchunk;
+    const int z1 = min(z0 + zchunk, zend);
     if (z0 >= z1) return;
     const size_t sxy = (size_t)sx * sy;
     // row bases at plane z0.  Row y0+nrows may be the boundary row sy-1: it is loaded like any other row
@@ -226,13 +230,17 @@ __global__ void __launch_bounds__(256) interpolate3d_kernel(real* __restrict__ f
 // (2i | 2i+1, 2py | 2py+1, 2pz | 2pz+1) from the 8 coarse values c[i..i+1][py..py+1][pz..pz+1] it loads once.
 // Fine accesses are contiguous per half-row (lane i -> even half index i and odd half index i); the
 // parity class of every point is a compile-time constant after unrolling, so there is no divergence.
+// Slab form: pz = pzbeg + blockIdx.z is a GLOBAL coarse plane; the fine / coarse arrays start at global
+// planes fzoff / czoff (0 for whole grids).  The host passes only pz whose fine planes 2pz, 2pz+1 are
+// owned and interior-or-skipped (z = 0 is skipped here, z <= fz-2 follows from pz <= cz-2).
 template <class real, bool ADD>
-__global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict__ fine, int fx, int fy, int fz,
-                                                               const real* __restrict__ coarse, int cx, int cy) {
+__global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict__ fine, int fx, int fy, int fzoff,
+                                                               const real* __restrict__ coarse, int cx, int cy, int czoff,
+                                                               int pzbeg) {
     const int FH = (fx + 1) >> 1, CH = (cx + 1) >> 1;
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int py = blockIdx.y * blockDim.y + threadIdx.y;
-    const int pz = blockIdx.z;
+    const int pz = pzbeg + blockIdx.z;
     if (i >= FH - 1 || py >= cy - 1) return;  // fine x = 2i+1 <= fx-2, fine y = 2py+1 <= fy-2
     const size_t cxy = (size_t)cx * cy, fxy = (size_t)fx * fy;
     real c[2][2][2];
@@ -242,7 +250,7 @@ __global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict_
         for (int dy = 0; dy < 2; dy++)
 #pragma unroll
             for (int dx = 0; dx < 2; dx++)
-                c[dx][dy][dz] = coarse[XSplit::pos(i + dx, CH) + (size_t)(py + dy) * cx + (size_t)(pz + dz) * cxy];
+                c[dx][dy][dz] = coarse[XSplit::pos(i + dx, CH) + (size_t)(py + dy) * cx + (size_t)(pz + dz - czoff) * cxy];
     auto get = [&](int dx, int dy, int dz) { return c[dx][dy][dz]; };
 #pragma unroll
     for (int dz = 0; dz < 2; dz++) {
@@ -252,7 +260,7 @@ __global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict_
         for (int dy = 0; dy < 2; dy++) {
             const int y = 2 * py + dy;
             if (y < 1) continue;
-            const size_t row = (size_t)y * fx + (size_t)z * fxy;
+            const size_t row = (size_t)y * fx + (size_t)(z - fzoff) * fxy;
             const real e0 = interpolate3d_point<real>(0, dy, dz, get);
             const real e1 = interpolate3d_point<real>(1, dy, dz, get);
             if (i >= 1) fine[row + i] = ADD ? fine[row + i] + e0 : e0;   // x = 2i
@@ -317,10 +325,12 @@ template <class real, class L, int MODE, int CTX, int CTY>
 __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __restrict__ v, const real* __restrict__ f,
                                                                   int sx, int sy, int sz, real hx2, real hy2, real hz2,
                                                                   real* __restrict__ coarse, int cx, int cy, int cz,
-                                                                  int pzchunk) {
+                                                                  int pzchunk, int fzoff, int czoff, int pzbeg, int pzend) {
+    // sz / cz are the GLOBAL plane counts; the fine arrays start at global plane fzoff and the coarse
+    // array at global plane czoff (0 for whole grids); coarse planes [pzbeg, pzend) are produced.
     constexpr int FX = 2 * CTX + 1, FY = 2 * CTY + 1;
     __shared__ real res[4][FY][FX + 1];
-    const int pz0 = blockIdx.z * pzchunk, pz1 = min(pz0 + pzchunk, cz);
+    const int pz0 = pzbeg + blockIdx.z * pzchunk, pz1 = min(pz0 + pzchunk, pzend);
     const int px0 = blockIdx.x * CTX, py0 = blockIdx.y * CTY;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     const int nthreads = blockDim.x * blockDim.y;
@@ -343,7 +353,7 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
             const int gx = gx0 + lx, gy = gy0 + ly;
             in[k] = zin && t < FX * FY && gx >= 1 && gx < sx - 1 && gy >= 1 && gy < sy - 1;
             if (in[k]) {
-                const size_t row = (size_t)gy * sx + (size_t)gz * sxy;
+                const size_t row = (size_t)gy * sx + (size_t)(gz - fzoff) * sxy;
                 const size_t i = row + L::pos(gx, H);
                 O[k] = v[row + L::pos(gx - 1, H)];
                 E[k] = v[row + L::pos(gx + 1, H)];
@@ -377,7 +387,7 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
             const int ty = t / CTX, tx = t - ty * CTX;
             const int px = px0 + tx, py = py0 + ty;
             if (px >= cx || py >= cy) continue;
-            const size_t ci = L::pos(px, CH) + (size_t)py * cx + (size_t)pz * cx * cy;
+            const size_t ci = L::pos(px, CH) + (size_t)py * cx + (size_t)(pz - czoff) * cx * cy;
             if (px == 0 || px == cx - 1 || py == 0 || py == cy - 1 || !zinterior) {
                 coarse[ci] = (real)0;  // injection of a boundary residual, which is 0 (:704-705 then :113-119)
                 continue;
@@ -437,46 +447,51 @@ static int relax3d_natural(mgx_ctx* ctx, real* v, const real* f, const int n[3],
 }
 
 template <class real, int TYW, int R>
-static void launch_xs(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int colour,
-                      int zchunk) {
-    const int H = (n[0] + 1) / 2;
-    const int gx = ceil_div(H - 1, 64), gy = ceil_div(n[1] - 2, TYW * R), gz = ceil_div(n[2] - 2, zchunk);
+static void launch_xs(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
+                      real hz2, int colour, int zchunk) {
+    const int H = (sx + 1) / 2;
+    const int gx = ceil_div(H - 1, 64), gy = ceil_div(sy - 2, TYW * R), gz = ceil_div(zend - zbeg, zchunk);
     const unsigned nblocks = ctx->relax_xcd == 2 ? 8u * ((gx * gy + 7) / 8) * gz : (unsigned)gx * gy * gz;
     hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
-                       (const real*)v, v, f, n[0], n[1], n[2], hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
+                       (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
 }
 
 template <class real, int TYW>
-static void launch_xs_rows(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int colour,
-                           int zchunk, int rows) {
+static void launch_xs_rows(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
+                           real hz2, int colour, int zchunk, int rows) {
     switch (rows) {
-        case 1: launch_xs<real, TYW, 1>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
-        case 2: launch_xs<real, TYW, 2>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
-        case 8: launch_xs<real, TYW, 8>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
-        default: launch_xs<real, TYW, 4>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk); break;
+        case 1: launch_xs<real, TYW, 1>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk); break;
+        case 2: launch_xs<real, TYW, 2>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk); break;
+        case 8: launch_xs<real, TYW, 8>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk); break;
+        default: launch_xs<real, TYW, 4>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk); break;
+    }
+}
+
+// one colour pass over the local planes [zbeg, zend) of an x-split array with sx x sy rows
+template <class real>
+static void relax3d_xs_pass(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
+                            real hz2, int colour) {
+    if (zend <= zbeg || sx < 3 || sy < 3) return;
+    int ty = ctx->relax_ty, rows = ctx->relax_rows, zchunk = ctx->relax_zchunk;
+    while (rows > 1 && rows * ty > sy - 2) rows >>= 1;  // small levels: do not idle most of a block
+    while (ty > 1 && rows * ty > sy - 2) ty >>= 1;
+    if (zchunk <= 0) {
+        const long long tiles = (long long)ceil_div((sx + 1) / 2 - 1, 64) * ceil_div(sy - 2, ty * rows);
+        zchunk = 4;  // measured best at 513^3 (tools/sweep_relax.py): short chunks, many blocks
+        while (zchunk > 1 && tiles * ceil_div(zend - zbeg, zchunk) < 8LL * ctx->num_cus) zchunk >>= 1;
+    }
+    switch (ty) {
+        case 1: launch_xs_rows<real, 1>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, rows); break;
+        case 2: launch_xs_rows<real, 2>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, rows); break;
+        case 8: launch_xs_rows<real, 8>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, rows); break;
+        default: launch_xs_rows<real, 4>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, rows); break;
     }
 }
 
 template <class real>
 static int relax3d_xsplit(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int ncycles) {
-    int ty = ctx->relax_ty, rows = ctx->relax_rows, zchunk = ctx->relax_zchunk;
-    while (rows > 1 && rows * ty > n[1] - 2) rows >>= 1;  // small levels: do not idle most of a block
-    while (ty > 1 && rows * ty > n[1] - 2) ty >>= 1;
-    if (zchunk <= 0) {
-        // enough z-chunks to give every CU several blocks; long enough chunks to amortise the 2-plane prologue
-        const long long tiles = (long long)ceil_div((n[0] + 1) / 2 - 1, 64) * ceil_div(n[1] - 2, ty * rows);
-        zchunk = 4;  // measured best at 513^3 (tools/sweep_relax.py): short chunks, many blocks
-        while (zchunk > 1 && tiles * ceil_div(n[2] - 2, zchunk) < 8LL * ctx->num_cus) zchunk >>= 1;
-    }
     for (int k = 0; k < ncycles; k++)
-        for (int colour = 0; colour < 2; colour++) {
-            switch (ty) {
-                case 1: launch_xs_rows<real, 1>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk, rows); break;
-                case 2: launch_xs_rows<real, 2>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk, rows); break;
-                case 8: launch_xs_rows<real, 8>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk, rows); break;
-                default: launch_xs_rows<real, 4>(ctx, v, f, n, hx2, hy2, hz2, colour, zchunk, rows); break;
-            }
-        }
+        for (int colour = 0; colour < 2; colour++) relax3d_xs_pass<real>(ctx, v, f, n[0], n[1], 1, n[2] - 1, hx2, hy2, hz2, colour);
     return MGX_OK;
 }
 
@@ -533,7 +548,7 @@ int interpolate3d(mgx_ctx* ctx, real* fine, const int fn[3], const real* coarse,
     if (st) return st;
     if (L::xsplit)
         hipLaunchKernelGGL((interpolate3d_xs_kernel<real, ADD>), grd((fn[0] + 1) / 2 - 1, cn[1] - 1, cn[2] - 1), blk(), 0,
-                           ctx->compute, fine, fn[0], fn[1], fn[2], coarse, cn[0], cn[1]);
+                           ctx->compute, fine, fn[0], fn[1], 0, coarse, cn[0], cn[1], 0, 0);
     else
         hipLaunchKernelGGL((interpolate3d_kernel<real, L, ADD>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute,
                            fine, fn[0], fn[1], fn[2], coarse, cn[0], cn[1]);
@@ -584,10 +599,10 @@ int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[
     dim3 g(ceil_div(cn[0], CTX), ceil_div(cn[1], CTY), ceil_div(cn[2], pzchunk));
     if (mode == MGX_RESIDUAL_REF_COMPAT)
         hipLaunchKernelGGL((residual_restrict3d_kernel<real, L, 0, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1],
-                           n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk);
+                           n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, 0, 0, 0, cn[2]);
     else
         hipLaunchKernelGGL((residual_restrict3d_kernel<real, L, 1, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1],
-                           n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk);
+                           n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, 0, 0, 0, cn[2]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -619,6 +634,67 @@ int relayout3d(mgx_ctx* ctx, const real* src, real* dst, const int n[3]) {
     int st = check_n3(n, "relayout3d");
     if (st) return st;
     hipLaunchKernelGGL((relayout3d_kernel<real, LS, LD>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, src, dst, n[0], n[1]);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+// ------------------------------------------------------------------ z-slab forms (multi-GPU)
+// A slab is a local array of consecutive z-planes of an (sx, sy, szg) level, starting at global plane
+// zoff, x-split layout.  Planes the caller does not list as "to update" act as ghost / boundary planes.
+template <class real>
+int relax3d_colour_slab(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, const real h[3], int colour, int zbeg,
+                        int zend, int zoff) {
+    MGX_REQUIRE(ctx && v && f && h, MGX_ERR_INVALID, "relax_colour_slab: NULL argument");
+    MGX_REQUIRE(valid_size(sx) && valid_size(sy), MGX_ERR_SIZE, "relax_colour_slab: sizes %d x %d are not 2^k+1", sx, sy);
+    MGX_REQUIRE((colour == 0 || colour == 1) && zbeg >= 1 && zend >= zbeg && zoff >= 0, MGX_ERR_INVALID,
+                "relax_colour_slab: bad colour / plane range");
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    relax3d_xs_pass<real>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, (colour + zoff) & 1);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+template <class real>
+int residual_restrict3d_slab(mgx_ctx* ctx, const real* v, const real* f, const int n[3], int fzoff, const real h[3],
+                             int mode, real* coarse_f, const int cn[3], int czoff, int pzbeg, int pzend) {
+    MGX_REQUIRE(ctx && v && f && h && coarse_f, MGX_ERR_INVALID, "residual_restrict_slab: NULL argument");
+    int st = check_n3(n, "residual_restrict_slab");
+    if (st) return st;
+    st = check_coarse3(n, cn, "residual_restrict_slab");
+    if (st) return st;
+    MGX_REQUIRE(mode == MGX_RESIDUAL_REF_COMPAT || mode == MGX_RESIDUAL_CORRECT, MGX_ERR_INVALID, "bad residual mode %d", mode);
+    MGX_REQUIRE(pzbeg >= 0 && pzend <= cn[2] && pzbeg <= pzend && fzoff >= 0 && czoff >= 0 && czoff <= pzbeg, MGX_ERR_INVALID,
+                "residual_restrict_slab: bad plane range");
+    if (pzbeg == pzend) return MGX_OK;
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    constexpr int CTX = 32, CTY = 8;
+    const int tiles = ceil_div(cn[0], CTX) * ceil_div(cn[1], CTY);
+    int pzchunk = ctx->rr_pzchunk > 0 ? ctx->rr_pzchunk : 8;
+    while (pzchunk > 1 && (long long)tiles * ceil_div(pzend - pzbeg, pzchunk) < 4LL * ctx->num_cus) pzchunk >>= 1;
+    dim3 g(ceil_div(cn[0], CTX), ceil_div(cn[1], CTY), ceil_div(pzend - pzbeg, pzchunk));
+    if (mode == MGX_RESIDUAL_REF_COMPAT)
+        hipLaunchKernelGGL((residual_restrict3d_kernel<real, XSplit, 0, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0],
+                           n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend);
+    else
+        hipLaunchKernelGGL((residual_restrict3d_kernel<real, XSplit, 1, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0],
+                           n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+template <class real>
+int interpolate_correct3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff, const real* coarse_v, const int cn[3],
+                               int czoff, int pzbeg, int pzend) {
+    MGX_REQUIRE(ctx && v && coarse_v, MGX_ERR_INVALID, "interpolate_correct_slab: NULL argument");
+    int st = check_n3(n, "interpolate_correct_slab");
+    if (st) return st;
+    st = check_coarse3(n, cn, "interpolate_correct_slab");
+    if (st) return st;
+    MGX_REQUIRE(pzbeg >= 0 && pzend <= cn[2] - 1 && pzbeg <= pzend && fzoff >= 0 && czoff >= 0 && czoff <= pzbeg, MGX_ERR_INVALID,
+                "interpolate_correct_slab: bad plane range");
+    if (pzbeg == pzend) return MGX_OK;
+    hipLaunchKernelGGL((interpolate3d_xs_kernel<real, true>), grd((n[0] + 1) / 2 - 1, cn[1] - 1, pzend - pzbeg), blk(), 0,
+                       ctx->compute, v, n[0], n[1], fzoff, coarse_v, cn[0], cn[1], czoff, pzbeg);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -678,6 +754,21 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
     }
 
 #define MGX_DEFINE_MISC3D(SFX, real)                                                                             \
+    int mgx3dxs_relax_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, const real h[3],   \
+                                        int colour, int zbeg, int zend, int zoff) {                              \
+        return mgx::relax3d_colour_slab<real>(ctx, v, f, sx, sy, h, colour, zbeg, zend, zoff);                   \
+    }                                                                                                            \
+    int mgx3dxs_residual_restrict_slab_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[3],         \
+                                             int fzoff, const real h[3], int mode, real* coarse_f,               \
+                                             const int cn[3], int czoff, int pzbeg, int pzend) {                 \
+        return mgx::residual_restrict3d_slab<real>(ctx, v, f, n, fzoff, h, mode, coarse_f, cn, czoff, pzbeg,     \
+                                                   pzend);                                                       \
+    }                                                                                                            \
+    int mgx3dxs_interpolate_correct_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff,                 \
+                                               const real* coarse_v, const int cn[3], int czoff, int pzbeg,      \
+                                               int pzend) {                                                      \
+        return mgx::interpolate_correct3d_slab<real>(ctx, v, n, fzoff, coarse_v, cn, czoff, pzbeg, pzend);       \
+    }                                                                                                            \
     int mgx3dxs_pack_##SFX(mgx_ctx* ctx, const real* natural, real* xsplit, const int n[3]) {                    \
         return mgx::relayout3d<real, mgx::Natural, mgx::XSplit>(ctx, natural, xsplit, n);                        \
     }                                                                                                            \

@@ -546,6 +546,106 @@ class MultiGrid1D(_MGBase):
         return grid
 
 
+# --------------------------------------------------------------------------- z-slab decomposition
+class SlabPlan(C.Structure):
+    _fields_ = [("zlo", C.c_int), ("zhi", C.c_int), ("glo", C.c_int), ("ghi", C.c_int), ("zoff", C.c_int), ("nzl", C.c_int),
+                ("ubeg", C.c_int), ("uend", C.c_int)]
+
+
+def dist_num_levels(sizeZ, nranks, numGrids, min_planes=4):
+    return lib.mg_dist_num_levels(int(sizeZ), int(nranks), int(numGrids), int(min_planes))
+
+
+def slab_plan(sizeZ, rank, nranks):
+    p = SlabPlan()
+    check(lib.mg_slab_plan(int(sizeZ), int(rank), int(nranks), C.byref(p)))
+    return p
+
+
+class LocalGroup:
+    """In-process test transport: `nranks` host threads, one Context each, same device (mgx_comm_init_local)."""
+
+    def __init__(self, nranks):
+        self._g = C.c_void_p()
+        check(lib.mgx_local_group_create(int(nranks), C.byref(self._g)))
+        self.nranks = nranks
+
+    def attach(self, ctx, rank):
+        check(lib.mgx_comm_init_local(ctx._h, self._g, int(rank)))
+
+    def close(self):
+        if self._g:
+            lib.mgx_local_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+
+def _dist_struct(ct):
+    class Slab3D(C.Structure):
+        _fields_ = [("d_v", C.c_void_p), ("d_f", C.c_void_p), ("sizeXYZ", C.c_int * 3), ("plan", SlabPlan), ("h_x", ct),
+                    ("h_y", ct), ("h_z", ct), ("x_a", ct), ("y_a", ct), ("z_a", ct)]
+
+    class DistMultiGrid3D(C.Structure):
+        _fields_ = [("slabs", C.POINTER(C.POINTER(Slab3D))), ("numDist", C.c_int), ("numGrids", C.c_int), ("maxGrids", C.c_int),
+                    ("tail", C.c_void_p), ("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
+                    ("residual_mode", C.c_int), ("d_share", C.c_void_p)]
+
+    return Slab3D, DistMultiGrid3D
+
+
+class DistMultiGrid3D(_MGBase):
+    """One rank's part of a z-slab decomposed 3D hierarchy (include/mg_multigrid.h, mgDistMultiGrid3D_<r>).
+    The context must already carry a communicator (Context.comm_init for RCCL, LocalGroup.attach for the
+    in-process test transport) unless it runs alone."""
+    _prefix = "mgDistMultiGrid3D"
+
+    def __init__(self, ctx, finestGridSizeXYZ, rng, dtype=np.float64, nlevels=0, residual_mode=REF_COMPAT, min_planes=4):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        self._sfx, self._ct = _ct(dtype)
+        self._S, self._M = _dist_struct(self._ct)
+        self._mg = C.POINTER(self._M)()
+        self.n = tuple(int(k) for k in finestGridSizeXYZ)
+        fn = getattr(lib, "mgDistMultiGrid3D_%s_create" % self._sfx)
+        check(fn(ctx._h, _ip(finestGridSizeXYZ), _rp(rng, self._ct), C.c_int(min_planes), C.byref(self._mg)))
+        if nlevels:
+            self.numGrids = nlevels
+        self._mg.contents.residual_mode = int(residual_mode)
+
+    @property
+    def numDist(self):
+        return self._mg.contents.numDist
+
+    @property
+    def rank(self):
+        return self._mg.contents.rank
+
+    @property
+    def nranks(self):
+        return self._mg.contents.nranks
+
+    def plan(self, gridID=0):
+        return self._mg.contents.slabs[gridID].contents.plan
+
+    def Relax(self, gridID, ncycles):
+        self._call("Relax", C.c_int(gridID), C.c_int(ncycles))
+
+    def FullMultiGridVCycle(self, *a):
+        raise NotImplementedError("the slab-decomposed path implements VCycle (the measured unit); FMG runs on one GPU")
+
+    def upload_v(self, gridID, full):
+        full = np.ascontiguousarray(full, self.dtype)
+        self._call("upload_v", C.c_int(gridID), full.ctypes.data_as(C.c_void_p))
+
+    def upload_f(self, gridID, full):
+        full = np.ascontiguousarray(full, self.dtype)
+        self._call("upload_f", C.c_int(gridID), full.ctypes.data_as(C.c_void_p))
+
+    def download_v_into(self, gridID, full):
+        """writes this rank's owned planes into `full` (a whole-grid array in the reference layout)"""
+        assert full.dtype == self.dtype and full.flags.c_contiguous
+        self._call("download_v", C.c_int(gridID), full.ctypes.data_as(C.c_void_p))
+
+
 # --------------------------------------------------------------------------- solve(grid, rhs, nlevels)
 def solve3d(ctx, grid, rhs, rng, nlevels=0, fmg=False, v0=1, v1=2, v2=2, ncycles=1, residual_mode=REF_COMPAT):
     grid = np.ascontiguousarray(grid).copy()

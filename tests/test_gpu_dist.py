@@ -1,0 +1,98 @@
+"""GPU suite: the slab-decomposed V-cycle driver (csrc/host/mg_dist3d.inc) with the real HIP kernels.
+The gpurun box has one GPU, so the ranks are host threads of this process, one context each on the same
+device, joined by the in-process test transport (mgx_comm_init_local: device-to-device copies + pthread
+barrier instead of RCCL send/recv).  Everything else -- slab plan, ghost handling, z-range kernels,
+agglomeration through the replicated tail -- is the production code.  Bar: bit-identical to the
+single-GPU hierarchy and to the oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle as O
+import pde_multigrid_amd as P
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+R3 = [0, 1, 0, 1, 0, 1]
+
+
+def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COMPAT, v0=None, f0=None, nlevels=0):
+    ctxs = [P.Context(0) for _ in range(nranks)]
+    group = P.LocalGroup(nranks)
+    for r, c in enumerate(ctxs):
+        group.attach(c, r)
+    full = np.full(tuple(reversed(n3)), np.nan, dtype)
+    errors, info = [], {}
+
+    def worker(r):
+        try:
+            mg = P.DistMultiGrid3D(ctxs[r], n3, rng, dtype, nlevels=nlevels, residual_mode=mode, min_planes=min_planes)
+            info[r] = (mg.numDist, mg.numGrids)
+            if f0 is not None:
+                mg.upload_f(0, f0)
+            if v0 is not None:
+                mg.upload_v(0, v0)
+            for _ in range(cycles):
+                mg.VCycle(0, v1, v2)
+            mg.download_v_into(0, full)
+            mg.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    alive = [t for t in threads if t.is_alive()]
+    assert not errors, errors
+    assert not alive, "a rank is stuck in an exchange (another rank failed or the schedule is unbalanced)"
+    for c in ctxs:
+        c.close()
+    group.close()
+    return full, info
+
+
+@pytest.mark.timeout(150)
+@pytest.mark.parametrize("nranks", [1, 2, 4])
+@pytest.mark.parametrize("n,min_planes", [(33, 2), (65, 4), (65, 2)])
+def test_dist_vcycle_matches_single_gpu_and_oracle(nranks, n, min_planes):
+    got, info = run_ranks(nranks, [n] * 3, R3, np.float64, 2, 2, 2, min_planes)
+    assert info[0][0] == P.dist_num_levels(n, nranks, O.num_grids(n), min_planes) >= 1
+    want = O.cycle3d([n] * 3, R3, mode=0, v1=2, v2=2, reps=2, dtype=np.float64)
+    assert not np.isnan(got).any()
+    assert bits_equal(got, want)
+
+
+@pytest.mark.timeout(150)
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_dist_vcycle_random_inputs_f32_and_correct_mode(nranks):
+    n3 = [65, 33, 65]  # anisotropic in y: slabs are along z
+    rng = np.random.default_rng(nranks)
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    v0 = rng.uniform(-1, 1, O.shape(n3)).astype(np.float32)
+    f0 = rng.uniform(-1, 1, O.shape(n3)).astype(np.float32)
+    for mode in (P.REF_COMPAT, P.CORRECT):
+        got, _ = run_ranks(nranks, n3, rg, np.float32, 1, 2, 1, 4, mode=mode, v0=v0, f0=f0)
+        want = O.cycle3d(n3, rg, mode=0, v1=1, v2=2, reps=1, v=v0, f=f0, residual_mode=mode, dtype=np.float32)
+        assert bits_equal(got, want)
+
+
+@pytest.mark.timeout(200)
+def test_dist_vcycle_8_ranks_129(known_answers):
+    """8 slabs of 16 planes at 129^3 (the 8-GPU shape of the node), reference semantics in fp32"""
+    got, info = run_ranks(8, [129] * 3, R3, np.float32, 2, 2, 1, 4)
+    assert info[0][0] == 3  # 129 (16 planes/rank), 65 (8) and 33 (4) stay distributed; 17 and coarser are replicated
+    want = O.cycle3d([129] * 3, R3, mode=0, v1=2, v2=2, reps=1, dtype=np.float32)
+    assert bits_equal(got, want)
+
+
+@pytest.mark.timeout(150)
+def test_dist_numgrids_override_and_relax_only():
+    got, _ = run_ranks(2, [65] * 3, R3, np.float64, 3, 0, 1, 4, nlevels=1)   # numGrids := 1 -> smoother only
+    want = O.cycle3d([65] * 3, R3, nlevels=1, mode=0, v1=3, v2=0, dtype=np.float64)
+    assert bits_equal(got, want)
+    got, _ = run_ranks(2, [65] * 3, R3, np.float64, 2, 2, 1, 4, nlevels=3)   # cycle ends on a distributed level
+    want = O.cycle3d([65] * 3, R3, nlevels=3, mode=0, v1=2, v2=2, dtype=np.float64)
+    assert bits_equal(got, want)
