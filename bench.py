@@ -3,16 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-Workload (BASELINE.json configs[3]): 3D Poisson, 513 points per axis ("512^3"), fp64, native
-9-level hierarchy, analytic RHS of the reference (Grid3D::InitF), v = 0.  One step = one
-VCycle(0, 2, 2) through the C host layer (include/mg_multigrid.h) with the inputs resident in HBM.
+Workload
+  N = 1 : BASELINE.json configs[3]: 3D Poisson, 513 points per axis ("512^3"), fp64, native 9-level
+          hierarchy, analytic RHS of the reference (Grid3D::InitF), v = 0, reference (REF_COMPAT) semantics.
+  N > 1 : BASELINE.json configs[4]: the same problem at 1025 points per axis ("1024^3"), ONE hierarchy
+          decomposed into z-slabs over the N GPUs (ghost planes over RCCL/xGMI, coarse levels replicated after an
+          all-gather) -- strong scaling: the total work does not depend on N.  `--n` overrides the size.
+One step = one VCycle(0, 2, 2) through the C host layer (include/mg_multigrid.h), inputs resident in HBM.
     MLUPS = (v1+v2) * sum_levels (n_l - 2)^3 * steps / seconds          
-roofline: the dominant kernel is the red-black Gauss-Seidel smoother on the finest level; its
-    algorithmic traffic is 3 reals per lattice update per red+black sweep = 24 B/LUP in fp64.
-    `achieved` = algorithmic bytes per launch / average launch duration, measured here with HIP
-    events on the stream the kernel runs on, over a smoother-only timed region.
-cpu_baseline: the oracle's CPU restatement ("port": same loop nest and single thread as the
-    reference) timed on this box's host cores on a bounded sample, rank 0 at N=1 only.
+roofline: the dominant kernel is the red-black Gauss-Seidel smoother on the finest level; its algorithmic
+    traffic is 3 reals per lattice update per red+black sweep = 24 B/LUP in fp64 (12 B per LUP of one colour
+    launch).  `achieved` = algorithmic bytes per launch / average launch duration, measured here with HIP events
+    on the stream the kernel runs on, over a smoother-only timed region (rank 0's slab when N > 1, without the
+    ghost exchange).
+cpu_baseline: the oracle's CPU restatement ("port": same loop nest and single thread as the reference) timed
+    on this box's host cores on a bounded sample, rank 0 at N = 1 only.
 """
 import argparse
 import json
@@ -23,9 +28,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_BPS = 8.0e12  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; about 6.3 TB/s achievable)
+R3 = [0, 1, 0, 1, 0, 1]
 
 
 def level_sizes(n, nlevels):
@@ -41,11 +45,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=513, help="points per axis of the finest grid (2^k+1)")
+    ap.add_argument("--n", type=int, default=0, help="points per axis of the finest grid (2^k+1); 0 = 513 (N=1) / 1025 (N>1)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--v1", type=int, default=2)
     ap.add_argument("--v2", type=int, default=2)
     ap.add_argument("--smoother-sweeps", type=int, default=20, help="sweeps in the smoother-only roofline region")
+    ap.add_argument("--min-planes", type=int, default=4, help="N>1: a level stays distributed while every GPU owns this many planes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -59,16 +64,31 @@ def main():
 
     dist = None
     if world > 1:
-        import torch.distributed as dist  # control plane only (barrier, max over ranks); data plane is RCCL in libmgx
+        # torch BEFORE libmgx (pde_multigrid_amd/_lib.py: load order of the ROCm runtime libraries)
+        import torch
+        import torch.distributed as dist  # control plane only (rendezvous, barrier, max over ranks); data plane = RCCL in libmgx
         dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import numpy as np
 
     import pde_multigrid_amd as P
 
     dtype = np.float64 if args.dtype == "f64" else np.float32
     wbytes = np.dtype(dtype).itemsize
+    n = args.n or (513 if world == 1 else 1025)
     ctx = P.Context(local_rank)
-    n = args.n
-    mg = P.MultiGrid3D(ctx, [n] * 3, [0, 1, 0, 1, 0, 1], dtype)  # every rank: one full replica (weak scaling)
+
+    if world == 1:
+        mg = P.MultiGrid3D(ctx, [n] * 3, R3, dtype)
+        reset = lambda: mg.setToValue_v(0, 0.0, True)  # noqa: E731
+        nd = 0
+    else:
+        uid = [P.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
+        mg = P.DistMultiGrid3D(ctx, [n] * 3, R3, dtype, min_planes=args.min_planes)
+        reset = lambda: mg.zero_v(0)  # noqa: E731
+        nd = mg.numDist
     nlev = mg.numGrids
     sizes = level_sizes(n, nlev)
     lups_per_cycle = (args.v1 + args.v2) * sum((s - 2) ** 3 for s in sizes)
@@ -77,9 +97,6 @@ def main():
         ctx.sync()
         if dist is not None:
             dist.barrier()
-
-    def reset():
-        mg.setToValue_v(0, 0.0, True)
 
     # ---- V-cycle throughput -----------------------------------------------------------
     reset()
@@ -93,84 +110,107 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
-    mlups = world * lups_per_cycle * args.steps / elapsed / 1e6
+    mlups = lups_per_cycle * args.steps / elapsed / 1e6  # one shared problem: whole-job rate
 
     # ---- smoother-only region for the roofline (HIP events on the compute stream) -------
     reset()
-    mg.Relax(0, 2)
     e0, e1 = ctx.event(), ctx.event()
-    ctx.sync()
-    ctx.record(e0)
-    mg.Relax(0, args.smoother_sweeps)
-    ctx.record(e1)
+    if world == 1:
+        mg.Relax(0, 2)
+        ctx.sync()
+        ctx.record(e0)
+        mg.Relax(0, args.smoother_sweeps)
+        ctx.record(e1)
+        my_lups_per_launch = (n - 2) ** 3 / 2.0
+        kname = "relax3d_xs_kernel<%s> (finest level, x-split layout, one colour per launch)"
+    else:
+        for c in (0, 1):
+            mg.relax_colour_local(0, c)
+        ctx.sync()
+        ctx.record(e0)
+        for _ in range(args.smoother_sweeps):
+            for c in (0, 1):
+                mg.relax_colour_local(0, c)
+        ctx.record(e1)
+        p = mg.plan(0)
+        my_lups_per_launch = (n - 2) ** 2 * (p.uend - p.ubeg) / 2.0
+        kname = "relax3d_xs_kernel<%s> (finest level, rank 0's z-slab, one colour per launch, ghost exchange excluded)"
     ms = ctx.elapsed_ms(e0, e1)
     launches = 2 * args.smoother_sweeps  # one launch per colour
-    lups_per_launch = (n - 2) ** 3 / 2.0
-    bytes_per_launch = 3 * wbytes * lups_per_launch  # 24 B/LUP fp64 per red+black sweep, half per colour launch
+    bytes_per_launch = 3 * wbytes * my_lups_per_launch  # 24 B/LUP fp64 per red+black sweep, half the points per colour launch
     launch_s = ms * 1e-3 / launches
     achieved = bytes_per_launch / launch_s
-    smoother_mlups = (n - 2) ** 3 * args.smoother_sweeps / (ms * 1e-3) / 1e6
+    smoother_mlups = 2 * my_lups_per_launch * args.smoother_sweeps / (ms * 1e-3) / 1e6
+    barrier()
 
-    if rank != 0:
-        return
-
-    out = {
-        "metric": "MLUPS on 3D Poisson 512^3 V-cycle",
-        "value": round(mlups, 1),
-        "unit": "MLUPS",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": args.dtype,
-        "data": "synthetic (analytic RHS of the reference: f = -3 pi^2 sin(pi x) sin(pi y) sin(pi z), v = 0)",
-        "config": {
-            "workload": "3D Poisson %d^3 points (%d^3 cells), %s, V(%d,%d) cycle, %d levels, 1 replica per GPU"
-                        % (n, n - 1, args.dtype, args.v1, args.v2, nlev),
-            "levels": sizes,
-            "lups_per_cycle": lups_per_cycle,
-            "parallelism": "single GPU" if world == 1 else "%d independent replicas (z-slab decomposition: see DESIGN.md)" % world,
-        },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "relax3d_xs_kernel<%s> (finest level, x-split layout, one colour per launch)" % ("double" if wbytes == 8 else "float"),
-            "achieved": round(achieved / 1e9, 1),
-            "peak": HBM_PEAK_BPS / 1e9,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_BPS, 4),
-            "traffic": None,
-            "algorithmic_bytes_per_launch": bytes_per_launch,
-            "avg_launch_us": round(launch_s * 1e6, 2),
-            "smoother_mlups": round(smoother_mlups, 1),
-        },
-    }
-
-    if world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as O  # CPU baseline leg only: the checker timed as a reported baseline
-        cn, clev, reps = 257, 6, 3
-        secs = O.time_vcycle3d(cn, clev, args.v1, args.v2, reps, dtype)
-        c_lups = (args.v1 + args.v2) * sum((s - 2) ** 3 for s in level_sizes(cn, clev)) * reps
-        out["cpu_baseline"] = {
-            "value": round(c_lups / secs / 1e6, 2),
+    if rank == 0:
+        out = {
+            "metric": "MLUPS on 3D Poisson 512^3 V-cycle" if n == 513 else "MLUPS on 3D Poisson %d^3 V-cycle" % (n - 1),
+            "value": round(mlups, 1),
             "unit": "MLUPS",
-            "cores": 1,
-            "kind": "port",
-            "sample": "%d V(%d,%d) cycles, 3D Poisson %d^3 %s, %d levels, oracle CPU restatement (-O2, reference loop nest, "
-                      "1 thread of %d host cores), %.1f s" % (reps, args.v1, args.v2, cn, args.dtype, clev, os.cpu_count() or 0, secs),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (analytic RHS of the reference: f = -3 pi^2 sin(pi x) sin(pi y) sin(pi z), v = 0)",
+            "config": {
+                "workload": "3D Poisson %d^3 points (%d^3 cells), %s, V(%d,%d) cycle, %d levels%s"
+                            % (n, n - 1, args.dtype, args.v1, args.v2, nlev,
+                               "" if world == 1 else ", one hierarchy in %d z-slabs" % world),
+                "levels": sizes,
+                "lups_per_cycle": lups_per_cycle,
+                "parallelism": "single GPU" if world == 1 else
+                               "z-slab decomposition over %d GPUs: %d distributed levels (ghost planes over RCCL), %d replicated"
+                               % (world, nd, nlev - nd),
+                "note": "N=1 runs BASELINE configs[3] (513^3); N>1 runs configs[4] (1025^3) as one strong-scaled problem",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": kname % ("double" if wbytes == 8 else "float"),
+                "achieved": round(achieved / 1e9, 1),
+                "peak": HBM_PEAK_BPS / 1e9,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_BPS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "avg_launch_us": round(launch_s * 1e6, 2),
+                "smoother_mlups_this_gpu": round(smoother_mlups, 1),
+            },
         }
-    print(json.dumps(out))
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if world == 1 and n == 513 and args.dtype == "f64" and os.path.exists(pmc):
+            # HBM bytes per launch of the same kernel from the separate rocprofv3 --pmc passes (tools/pmc_summary.py):
+            # 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md
+            with open(pmc) as fh:
+                out["roofline"]["traffic"] = json.load(fh).get("relax3d_xs_kernel_f64_513_bytes_per_launch")
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as O  # CPU baseline leg only: the checker timed as a reported baseline
+            cn, clev, reps = 257, 6, 3
+            secs = O.time_vcycle3d(cn, clev, args.v1, args.v2, reps, dtype)
+            c_lups = (args.v1 + args.v2) * sum((s - 2) ** 3 for s in level_sizes(cn, clev)) * reps
+            out["cpu_baseline"] = {
+                "value": round(c_lups / secs / 1e6, 2),
+                "unit": "MLUPS",
+                "cores": 1,
+                "kind": "port",
+                "sample": "%d V(%d,%d) cycles, 3D Poisson %d^3 %s, %d levels, oracle CPU restatement (-O2, reference loop "
+                          "nest, 1 thread of %d host cores), %.1f s" % (reps, args.v1, args.v2, cn, args.dtype, clev,
+                                                                         os.cpu_count() or 0, secs),
+            }
+        print(json.dumps(out))
     mg.close()
     ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -132,6 +132,7 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
     int mgDistMultiGrid3D_##R##_InitF(mgDistMultiGrid3D_##R* mg, int gridID);                            \
     int mgDistMultiGrid3D_##R##_Relax(mgDistMultiGrid3D_##R* mg, int gridID, int ncycles);               \
     int mgDistMultiGrid3D_##R##_VCycle(mgDistMultiGrid3D_##R* mg, int gridID, int v1, int v2);           \
+    int mgDistMultiGrid3D_##R##_zero_v(mgDistMultiGrid3D_##R* mg, int gridID);                           \
     int mgDistMultiGrid3D_##R##_upload_v(mgDistMultiGrid3D_##R* mg, int gridID, const real* host_full);  \
     int mgDistMultiGrid3D_##R##_upload_f(mgDistMultiGrid3D_##R* mg, int gridID, const real* host_full);  \
     int mgDistMultiGrid3D_##R##_download_v(mgDistMultiGrid3D_##R* mg, int gridID, real* host_full);      \

@@ -224,6 +224,9 @@ int mgx_comm_wait(mgx_ctx* ctx);
  * double (residual norm).  Both enqueue on the comm stream with the same ordering rules. */
 int mgx_comm_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count, int elem_bytes);
 int mgx_comm_allreduce_sum_f64(mgx_ctx* ctx, double* dev_inout, size_t count);
+/* RCCL plumbing check usable on a single-GPU box: this rank sends `count` doubles to itself with a grouped
+ * ncclSend/ncclRecv on the comm stream (the exact call pattern of the halo exchange). */
+int mgx_comm_selftest(mgx_ctx* ctx, const double* dev_src, double* dev_dst, size_t count);
 
 #ifdef __cplusplus
 }

@@ -211,6 +211,25 @@ int mgx_comm_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count,
     return MGX_OK;
 }
 
+// Grouped ncclSend/ncclRecv of `count` doubles from this rank to itself on the comm stream, then an
+// all-gather and an all-reduce: exercises RCCL linkage, communicator and stream/event plumbing on a box
+// with a single GPU (nranks may be 1).  dev_src and dev_dst must not overlap.
+int mgx_comm_selftest(mgx_ctx* ctx, const double* dev_src, double* dev_dst, size_t count) {
+    MGX_REQUIRE(ctx && dev_src && dev_dst && count, MGX_ERR_INVALID, "NULL argument");
+    MGX_REQUIRE(ctx->rccl_comm, MGX_ERR_RCCL, "RCCL communicator not initialised");
+    int st = order_after_compute(ctx);
+    if (st) return st;
+    ncclComm_t comm = (ncclComm_t)ctx->rccl_comm;
+    MGX_NCCL(ncclGroupStart());
+    MGX_NCCL(ncclSend(dev_src, count, ncclFloat64, ctx->rank, comm, ctx->comm));
+    MGX_NCCL(ncclRecv(dev_dst, count, ncclFloat64, ctx->rank, comm, ctx->comm));
+    MGX_NCCL(ncclGroupEnd());
+    MGX_HIP(hipEventRecord(ctx->ev_comm, ctx->comm));
+    MGX_HIP(hipStreamWaitEvent(ctx->compute, ctx->ev_comm, 0));
+    MGX_HIP(hipStreamSynchronize(ctx->comm));
+    return MGX_OK;
+}
+
 int mgx_comm_allreduce_sum_f64(mgx_ctx* ctx, double* dev_inout, size_t count) {
     MGX_REQUIRE(ctx && dev_inout, MGX_ERR_INVALID, "NULL argument");
     if (ctx->nranks == 1) return MGX_OK;

@@ -629,6 +629,22 @@ class DistMultiGrid3D(_MGBase):
     def Relax(self, gridID, ncycles):
         self._call("Relax", C.c_int(gridID), C.c_int(ncycles))
 
+    def zero_v(self, gridID=0):
+        self._call("zero_v", C.c_int(gridID))
+
+    def slab(self, gridID=0):
+        return self._mg.contents.slabs[gridID].contents
+
+    def relax_colour_local(self, gridID, colour):
+        """one colour pass on this rank's slab WITHOUT the ghost exchange (kernel timing only)"""
+        g = self.slab(gridID)
+        p = g.plan
+        h = (self._ct * 3)(g.h_x, g.h_y, g.h_z)
+        check(getattr(lib, "mgx3dxs_relax_colour_slab_" + self._sfx)(self.ctx._h, C.c_void_p(g.d_v), C.c_void_p(g.d_f),
+                                                                      C.c_int(g.sizeXYZ[0]), C.c_int(g.sizeXYZ[1]), h,
+                                                                      C.c_int(colour), C.c_int(p.ubeg - p.zoff),
+                                                                      C.c_int(p.uend - p.zoff), C.c_int(p.zoff)))
+
     def FullMultiGridVCycle(self, *a):
         raise NotImplementedError("the slab-decomposed path implements VCycle (the measured unit); FMG runs on one GPU")
 

@@ -96,3 +96,26 @@ def test_dist_numgrids_override_and_relax_only():
     got, _ = run_ranks(2, [65] * 3, R3, np.float64, 2, 2, 1, 4, nlevels=3)   # cycle ends on a distributed level
     want = O.cycle3d([65] * 3, R3, nlevels=3, mode=0, v1=2, v2=2, dtype=np.float64)
     assert bits_equal(got, want)
+
+
+@pytest.mark.timeout(150)
+def test_rccl_plumbing_single_rank():
+    """RCCL itself cannot be run across GPUs on the one-GPU test box; this checks what can be checked there:
+    unique id, ncclCommInitRank, grouped send/recv on the comm stream, event ordering, teardown."""
+    import ctypes as C
+    ctx = P.Context(0)
+    ctx.comm_init(P.Context.unique_id(), 0, 1)
+    x = np.random.default_rng(0).uniform(-1, 1, 1 << 16)
+    src, dst = ctx.to_device(x), ctx.malloc(x.nbytes)
+    P.check(P.lib.mgx_comm_selftest(ctx._h, src, dst, C.c_size_t(x.size)))
+    assert bits_equal(ctx.to_host(dst, x.shape, x.dtype), x)
+    # with a (1-rank) RCCL communicator attached the slab driver still works
+    mg = P.DistMultiGrid3D(ctx, [33] * 3, R3, np.float64, min_planes=2)
+    mg.VCycle(0, 2, 2)
+    full = np.zeros((33, 33, 33))
+    mg.download_v_into(0, full)
+    assert bits_equal(full, O.cycle3d([33] * 3, R3, mode=0, dtype=np.float64))
+    mg.close()
+    ctx.free(src)
+    ctx.free(dst)
+    ctx.close()
