@@ -72,6 +72,8 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         int residual_mode; /* mgx_residual_mode */                                                       \
         int fuse;                                                                                        \
         int layout; /* device layout of d_v/d_f/d_r/d_e: 0 = reference layout, 1 = x-split (mgx.h) */    \
+        int smoother; /* 0 = red-black Gauss-Seidel (the reference), 1 = weighted Jacobi (addition) */   \
+        real omega;   /* Jacobi weight, default 2/3 */                                                   \
     } mgMultiGrid3D_##R;                                                                                 \
     int mgMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6],     \
                                    mgMultiGrid3D_##R** out);                                             \
@@ -100,6 +102,10 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
     int mgMultiGrid3D_##R##_download_f(mgMultiGrid3D_##R* mg, int gridID, real* host);                   \
     int mgMultiGrid3D_##R##_download_residual(mgMultiGrid3D_##R* mg, int gridID, real* host);            \
     int mgMultiGrid3D_##R##_ResidualNorm(mgMultiGrid3D_##R* mg, int gridID, double* l2);                 \
+    /* PrintDiff (N3/MultiGrid3D.cpp:760-764 -> Grid3D::PrintDiff) as numbers: mean |diff|, max |diff| and  */ \
+    /* relative L2 of diff = sin(pi x) sin(pi y) sin(pi z) - v over all points of level gridID              */ \
+    int mgMultiGrid3D_##R##_DiffStats(mgMultiGrid3D_##R* mg, int gridID, double* mean_abs,               \
+                                      double* max_abs, double* rel_l2);                                  \
     /* solve(grid, rhs, nlevels): host arrays in the reference layout; grid = initial guess incl.     */ \
     /* boundary values on input, solution on output; nlevels = 0 -> reference rule; ncycles V(v1,v2)  */ \
     /* cycles from the given guess, or one FullMultiGridVCycle(v0,v1,v2) when fmg != 0.               */ \
@@ -158,6 +164,8 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         int alfa;                                                                                        \
         mgx_ctx* ctx;                                                                                    \
         int fuse;                                                                                        \
+        int smoother; /* 0 = red-black Gauss-Seidel (the reference), 1 = weighted Jacobi (addition) */   \
+        real omega;                                                                                      \
     } mgMultiGrid2D_##R;                                                                                 \
     int mgMultiGrid2D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXY[2], const real range[4],     \
                                    const real* A, int A_size, int alfa, mgMultiGrid2D_##R** out);        \
@@ -182,6 +190,9 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
     int mgMultiGrid2D_##R##_upload_f(mgMultiGrid2D_##R* mg, int gridID, const real* host);               \
     int mgMultiGrid2D_##R##_download_v(mgMultiGrid2D_##R* mg, int gridID, real* host);                   \
     int mgMultiGrid2D_##R##_download_f(mgMultiGrid2D_##R* mg, int gridID, real* host);                   \
+    /* mean over the interior of |v - (2x^2-4xy+2y^2)| on the finest level (thesis Fig. 4.3 metric,     */ \
+    /* CUDA_TESI/CUDA Lyapunov 2D/Grid2D.cu:123-154)                                                    */ \
+    int mgMultiGrid2D_##R##_MeanAbsoluteError(mgMultiGrid2D_##R* mg, int gridID, double* mean);          \
     int mg2d_solve_##R(mgx_ctx* ctx, real* grid, const real* rhs, const int sizeXY[2],                   \
                        const real range[4], const real A[4], int alfa, int nlevels, int fmg, int v0,     \
                        int v1, int v2, int ncycles);                                                     \

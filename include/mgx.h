@@ -114,6 +114,14 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
  * mgx3d_interpolate_correct: v += Interpolate(coarse_v) on the interior.
  * mgx3d_init_f: f[x,y,z] = (real)(c * tx[x] * ty[y] * tz[z]) evaluated in double, left to
  *   right (Grid3D::InitF with host-computed sin tables; tables are host pointers).
+ * mgx3d_jacobi: ADDITION (north_star names weighted Jacobi; the reference has only red-black Gauss-Seidel):
+ *   `ncycles` sweeps of v <- v + omega*(u - v), u = the Gauss-Seidel value from the OLD iterate; `tmp` is a
+ *   second n-point array (ping-pong), the result always ends in v.  Parity unpinned by the reference.
+ * mgx3d_diff_stats: Grid3D::PrintDiff (N3/Grid3D.cpp:136-159) as a device reduction: diff = realSol - v with
+ *   realSol = (real)(tx[x]*ty[y]*tz[z]) (host sin tables); host_out = {sum|diff|, max|diff|, sum diff^2,
+ *   sum realSol^2} over all points.
+ * mgx2d_mean_abs_error: mean over the interior of |v - (2x^2-4xy+2y^2)| -- the accuracy metric of the thesis
+ *   (PrintMeanAbsoluteError, CUDA_TESI/CUDA Lyapunov 2D/Grid2D.cu:123-154), reduced on the device.
  * mgx3dxs_*: the same operators on the device-internal "x-split" layout
  *   idx = (x>>1) + (x&1)*((sx+1)/2) + y*sx + z*sx*sy
  *   (every x-row stored as its even-x half followed by its odd-x half; rows and planes in the
@@ -141,6 +149,10 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                                         const int cn[3]);                                               \
     int mgx3d_init_f_##SFX(mgx_ctx* ctx, real* f, const int n[3], double c, const double* host_tx,      \
                            const double* host_ty, const double* host_tz);                               \
+    int mgx3d_jacobi_##SFX(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[3],             \
+                           const real h[3], real omega, int ncycles);                                   \
+    int mgx3d_diff_stats_##SFX(mgx_ctx* ctx, const real* v, const int n[3], const double* host_tx,      \
+                               const double* host_ty, const double* host_tz, double host_out[4]);       \
     /* x-split twins: same operators on arrays whose x-rows are de-interleaved (see below) */           \
     int mgx3dxs_pack_##SFX(mgx_ctx* ctx, const real* natural, real* xsplit, const int n[3]);            \
     int mgx3dxs_unpack_##SFX(mgx_ctx* ctx, const real* xsplit, real* natural, const int n[3]);          \
@@ -161,6 +173,10 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                                           const int cn[3]);                                             \
     int mgx3dxs_init_f_##SFX(mgx_ctx* ctx, real* f, const int n[3], double c, const double* host_tx,    \
                              const double* host_ty, const double* host_tz);                             \
+    int mgx3dxs_jacobi_##SFX(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[3],           \
+                             const real h[3], real omega, int ncycles);                                 \
+    int mgx3dxs_diff_stats_##SFX(mgx_ctx* ctx, const real* v, const int n[3], const double* host_tx,    \
+                                 const double* host_ty, const double* host_tz, double host_out[4]);     \
     /* z-slab forms for the multi-GPU decomposition.  A slab is a local x-split array of consecutive */ \
     /* z-planes of a level whose GLOBAL sizes are n[] (cn[] for the coarse level); it starts at       */ \
     /* global plane zoff.  relax_colour_slab: ONE colour pass (colour 0 = red: (x+y+z_global) even)   */ \
@@ -187,6 +203,11 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx2d_apply_correction_##SFX(mgx_ctx* ctx, real* fine, const int fn[2], const real* err,        \
                                      const int en[2]);                                                  \
     int mgx2d_set_##SFX(mgx_ctx* ctx, real* grid, const int n[2], real value, int modify_boundaries);   \
+    int mgx2d_jacobi_##SFX(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[2],             \
+                           const real h[2], const real a[2], const real A[4], int alfa, real omega,     \
+                           int ncycles);                                                                \
+    int mgx2d_mean_abs_error_##SFX(mgx_ctx* ctx, const real* v, const int n[2], const real h[2],        \
+                                   const real a[2], double* host_mean);                                 \
     int mgx_norm2_##SFX(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq);
 
 MGX_DECLARE_OPS(f32, float)

@@ -86,6 +86,17 @@ void cycle1(int n, const real range[2], int nlevels, int mode, int v0, int v1, i
         geom3<real>(n, range, h, a);                                                                    \
         relax3_colour<real>(v, f, n, h, colour);                                                        \
     }                                                                                                   \
+    void mgo3d_jacobi_##SFX(const int n[3], const real range[6], real* v, const real* f, real omega, int ncycles) { \
+        real h[3], a[3];                                                                                \
+        geom3<real>(n, range, h, a);                                                                    \
+        jacobi3<real>(v, f, n, h, omega, ncycles);                                                      \
+    }                                                                                                   \
+    void mgo2d_jacobi_##SFX(const int n[2], const real range[4], const real A[4], int alfa, real* v,    \
+                            const real* f, real omega, int ncycles) {                                   \
+        real h[2], a[2];                                                                                \
+        geom2<real>(n, range, h, a);                                                                    \
+        jacobi2<real>(v, f, n, h, a, A, alfa, omega, ncycles);                                          \
+    }                                                                                                   \
     void mgo3d_residual_##SFX(const int n[3], const real range[6], const real* v, const real* f,        \
                               real* r, int mode) {                                                      \
         real h[3], a[3];                                                                                \

@@ -131,6 +131,30 @@ void relax3_colour(real* v, const real* f, const int n[3], const real h[3], int 
             }
 }
 
+// Weighted Jacobi sweeps (ADDITION: named by north_star, absent from the reference -- parity unpinned; this is the
+// restatement the HIP kernel is compared with): v <- v + omega*(u - v), u = the Gauss-Seidel value of :532
+// evaluated on the old iterate.
+template <class real>
+void jacobi3(real* v, const real* f, const int n[3], const real h[3], real omega, int ncycles) {
+    const int sx = n[0], sy = n[1], sz = n[2];
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    const size_t sxy = (size_t)sx * sy;
+    std::vector<real> old((size_t)sx * sy * sz);
+    for (int k = 0; k < ncycles; k++) {
+        memcpy(old.data(), v, old.size() * sizeof(real));
+        for (int z = 1; z < sz - 1; z++)
+            for (int y = 1; y < sy - 1; y++)
+                for (int x = 1; x < sx - 1; x++) {
+                    const size_t i = x + (size_t)y * sx + (size_t)z * sxy;
+                    const real O = old[i - 1], E = old[i + 1], N = old[i - sx], S = old[i + sx], D = old[i - sxy], U = old[i + sxy];
+                    const real u = (O * (hy2 * hz2) + E * (hy2 * hz2) + N * (hx2 * hz2) + S * (hx2 * hz2) + D * (hx2 * hy2) +
+                                    U * (hx2 * hy2) - f[i] * hx2 * hy2 * hz2) /
+                                   (2 * (hy2 * hz2 + hx2 * hz2 + hx2 * hy2));
+                    v[i] = old[i] + omega * (u - old[i]);
+                }
+    }
+}
+
 // CalculateResidual.  REF_COMPAT keeps the reference's sign quirk (-S, -U);
 // CORRECT uses +S, +U.                                   N3/MultiGrid3D.cpp:678-730 (:723)
 template <class real>
@@ -361,6 +385,29 @@ void relax2(real* v, const real* f, const int n[2], const real h[2], const real 
                     real den = K1 * hy + K2 * hx - alfa * hx * hy;                    // :236
                     v[i] = (hy * K1 * v[i + 1] + hx * K2 * v[i + sx] - f[i] * hx * hy) / (den);  // :241
                 }
+}
+
+// Weighted Jacobi, 2D (addition, see jacobi3)
+template <class real>
+void jacobi2(real* v, const real* f, const int n[2], const real h[2], const real a[2], const real A[4], int alfa, real omega,
+             int ncycles) {
+    const int sx = n[0], sy = n[1];
+    const real hx = h[0], hy = h[1];
+    std::vector<real> old((size_t)sx * sy);
+    for (int k = 0; k < ncycles; k++) {
+        memcpy(old.data(), v, old.size() * sizeof(real));
+        for (int y = 1; y < sy - 1; y++)
+            for (int x = 1; x < sx - 1; x++) {
+                const size_t i = x + (size_t)y * sx;
+                real xj = a[0] + x * hx;
+                real yi = a[1] + y * hy;
+                real K1 = A[0] * xj + A[1] * yi;
+                real K2 = A[2] * xj + A[3] * yi;
+                real den = K1 * hy + K2 * hx - alfa * hx * hy;
+                const real u = (hy * K1 * old[i + 1] + hx * K2 * old[i + sx] - f[i] * hx * hy) / (den);
+                v[i] = old[i] + omega * (u - old[i]);
+            }
+    }
 }
 
 // CalculateResidual (consistent with Relax).              N2/MultiGrid2D.cpp:367-408 (:403)

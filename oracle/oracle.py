@@ -120,6 +120,22 @@ def relax_colour3d(n, rng, v, f, colour, dtype=np.float32):
     return v
 
 
+def jacobi3d(n, rng, v, f, omega, ncycles, dtype=np.float32):
+    fn, ct = _fn("mgo3d_jacobi", dtype)
+    v = _arr(v, dtype).copy()
+    f = _arr(f, dtype)
+    fn(_ip(n), _rp(rng, ct), _p(v), _p(f), ct(omega), C.c_int(ncycles))
+    return v
+
+
+def jacobi2d(n, rng, A, alfa, v, f, omega, ncycles, dtype=np.float32):
+    fn, ct = _fn("mgo2d_jacobi", dtype)
+    v = _arr(v, dtype).copy()
+    f = _arr(f, dtype)
+    fn(_ip(n), _rp(rng, ct), _rp(A, ct), C.c_int(alfa), _p(v), _p(f), ct(omega), C.c_int(ncycles))
+    return v
+
+
 def residual3d(n, rng, v, f, mode=REF_COMPAT, dtype=np.float32):
     fn, ct = _fn("mgo3d_residual", dtype)
     v = _arr(v, dtype)

@@ -117,6 +117,54 @@ __global__ void __launch_bounds__(256) set2d_kernel(real* __restrict__ g, int sx
     g[x + (size_t)y * sx] = value;
 }
 
+// weighted Jacobi (addition, see mgx_kernels3d.hip): vout = v + omega*(u - v), u = the Gauss-Seidel value (:241)
+template <class real>
+__global__ void __launch_bounds__(256) jacobi2d_kernel(const real* __restrict__ v, real* __restrict__ vout,
+                                                       const real* __restrict__ f, int sx, int sy, Lyap2<real> k, real omega) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= sx || y >= sy) return;
+    const size_t i = x + (size_t)y * sx;
+    const real c = v[i];
+    if (x == 0 || x == sx - 1 || y == 0 || y == sy - 1) {
+        vout[i] = c;
+        return;
+    }
+    const real xj = k.ax + x * k.hx;
+    const real yi = k.ay + y * k.hy;
+    const real K1 = k.A0 * xj + k.A1 * yi;
+    const real K2 = k.A2 * xj + k.A3 * yi;
+    const real den = K1 * k.hy + K2 * k.hx - k.alfa * k.hx * k.hy;
+    const real u = (k.hy * K1 * v[i + 1] + k.hx * K2 * v[i + sx] - f[i] * k.hx * k.hy) / (den);
+    vout[i] = c + omega * (u - c);
+}
+
+// sum over the interior of |v - realsol|, realsol = 2*xj*xj-4*xj*yi+2*yi*yi in `real`
+// (PrintMeanAbsoluteError, CUDA_TESI/CUDA Lyapunov 2D/Grid2D.cu:123-154; the host divides by the point count)
+template <class real>
+__global__ void __launch_bounds__(256) abs_error2d_kernel(const real* __restrict__ v, int sx, int sy, real hx, real hy, real ax,
+                                                          real ay, double* __restrict__ out) {
+    const int y = 1 + blockIdx.y;
+    double s = 0;
+    for (int x = 1 + threadIdx.x; x < sx - 1; x += blockDim.x) {
+        const real xj = ax + x * hx;
+        const real yi = ay + y * hy;
+        const real realsol = 2 * xj * xj - 4 * xj * yi + 2 * yi * yi;
+        const real diff = v[x + (size_t)y * sx] - realsol;
+        s += fabs((double)diff);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0;
+        for (int w = 0; w < (int)((blockDim.x + 63) >> 6); w++) a += part[w];
+        atomicAdd(out, a);
+    }
+}
+
 // =========================================================================== host side
 static inline dim3 blk2() { return dim3(64, 4, 1); }
 static inline dim3 grd2(int nx, int ny) { return dim3(ceil_div(nx, 64), ceil_div(ny, 4), 1); }
@@ -224,6 +272,47 @@ int set2d(mgx_ctx* ctx, real* g, const int n[2], real value, int modify_boundari
     return MGX_OK;
 }
 
+template <class real>
+int jacobi2d(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[2], const real h[2], const real a[2], const real A[4],
+             int alfa, real omega, int ncycles) {
+    MGX_REQUIRE(ctx && v && tmp && f && h && a && A && v != tmp, MGX_ERR_INVALID, "jacobi2d: NULL or aliased argument");
+    int st = check_n2(n, "jacobi2d");
+    if (st) return st;
+    MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "jacobi2d: ncycles = %d < 0", ncycles);
+    const Lyap2<real> k = lyap<real>(h, a, A, alfa);
+    real *src = v, *dst = tmp;
+    for (int c = 0; c < ncycles; c++) {
+        hipLaunchKernelGGL((jacobi2d_kernel<real>), grd2(n[0], n[1]), blk2(), 0, ctx->compute, (const real*)src, dst, f, n[0], n[1],
+                           k, omega);
+        real* t = src; src = dst; dst = t;
+    }
+    MGX_LAUNCH_CHECK();
+    if (src != v) MGX_HIP(hipMemcpyAsync(v, src, sizeof(real) * (size_t)n[0] * n[1], hipMemcpyDeviceToDevice, ctx->compute));
+    return MGX_OK;
+}
+
+template <class real>
+int mean_abs_error2d(mgx_ctx* ctx, const real* v, const int n[2], const real h[2], const real a[2], double* host_mean) {
+    MGX_REQUIRE(ctx && v && h && a && host_mean, MGX_ERR_INVALID, "mean_abs_error2d: NULL argument");
+    int st = check_n2(n, "mean_abs_error2d");
+    if (st) return st;
+    void* ws = nullptr;
+    st = workspace(ctx, sizeof(double), &ws);
+    if (st) return st;
+    MGX_HIP(hipMemsetAsync(ws, 0, sizeof(double), ctx->compute));
+    if (n[0] > 2 && n[1] > 2) {
+        hipLaunchKernelGGL((abs_error2d_kernel<real>), dim3(1, n[1] - 2), dim3(n[0] >= 256 ? 256 : 64), 0, ctx->compute, v, n[0],
+                           n[1], h[0], h[1], a[0], a[1], (double*)ws);
+        MGX_LAUNCH_CHECK();
+    }
+    double total = 0;
+    MGX_HIP(hipMemcpyAsync(&total, ws, sizeof(double), hipMemcpyDeviceToHost, ctx->compute));
+    MGX_HIP(hipStreamSynchronize(ctx->compute));
+    const double cnt = (double)(n[0] - 2) * (double)(n[1] - 2);
+    *host_mean = cnt > 0 ? total / cnt : 0.0;
+    return MGX_OK;
+}
+
 }  // namespace mgx
 
 #define MGX_DEFINE_OPS2D(SFX, real)                                                                              \
@@ -247,6 +336,14 @@ int set2d(mgx_ctx* ctx, real* g, const int n[2], real value, int modify_boundari
     }                                                                                                            \
     int mgx2d_set_##SFX(mgx_ctx* ctx, real* grid, const int n[2], real value, int modify_boundaries) {           \
         return mgx::set2d<real>(ctx, grid, n, value, modify_boundaries);                                         \
+    }                                                                                                            \
+    int mgx2d_jacobi_##SFX(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[2], const real h[2],     \
+                           const real a[2], const real A[4], int alfa, real omega, int ncycles) {                \
+        return mgx::jacobi2d<real>(ctx, v, tmp, f, n, h, a, A, alfa, omega, ncycles);                            \
+    }                                                                                                            \
+    int mgx2d_mean_abs_error_##SFX(mgx_ctx* ctx, const real* v, const int n[2], const real h[2], const real a[2], \
+                                   double* host_mean) {                                                          \
+        return mgx::mean_abs_error2d<real>(ctx, v, n, h, a, host_mean);                                          \
     }
 
 extern "C" {

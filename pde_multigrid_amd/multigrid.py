@@ -245,6 +245,13 @@ class _Ops3D(_Ops):
         cn = coarse_size(n)
         return self._run(ctx, [v, coarse], lambda a, c: fn(ctx._h, a, _ip(n), c, _ip(cn)), 0, _shape(n), dtype)
 
+    def jacobi(self, ctx, v, f, n, rng, omega, ncycles, dtype=None):
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("jacobi", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        return self._run(ctx, [v, np.zeros_like(v), f], lambda a, t, b: fn(ctx._h, a, t, b, _ip(n), h, ct(omega), C.c_int(ncycles)),
+                         0, _shape(n), dtype)
+
     def norm2(self, ctx, x):
         s, _ = _ct(x.dtype)
         out = C.c_double()
@@ -271,6 +278,14 @@ class _Ops2D(_Ops):
         return self._run(ctx, [v, f], lambda x, y: fn(ctx._h, x, y, _ip(n), h, a, AA, C.c_int(alfa), C.c_int(ncycles)), 0,
                          _shape(n), dtype)
 
+    def jacobi(self, ctx, v, f, n, rng, A, alfa, omega, ncycles, dtype=None):
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("jacobi", dtype)
+        h, a, AA = self._geom(n, rng, A, dtype, ct)
+        return self._run(ctx, [v, np.zeros_like(v), f],
+                         lambda x, t, y: fn(ctx._h, x, t, y, _ip(n), h, a, AA, C.c_int(alfa), ct(omega), C.c_int(ncycles)), 0,
+                         _shape(n), dtype)
+
     def residual(self, ctx, v, f, n, rng, A, alfa, dtype=None):
         dtype = dtype or v.dtype
         fn, ct = self._fn("residual", dtype)
@@ -295,7 +310,8 @@ def _grid3_struct(ct):
 
     class MultiGrid3D(C.Structure):
         _fields_ = [("grids3D", C.POINTER(C.POINTER(Grid3D))), ("numGrids", C.c_int), ("maxGrids", C.c_int),
-                    ("ctx", C.c_void_p), ("residual_mode", C.c_int), ("fuse", C.c_int), ("layout", C.c_int)]
+                    ("ctx", C.c_void_p), ("residual_mode", C.c_int), ("fuse", C.c_int), ("layout", C.c_int),
+                    ("smoother", C.c_int), ("omega", ct)]
 
     return Grid3D, MultiGrid3D
 
@@ -308,7 +324,8 @@ def _grid2_struct(ct):
 
     class MultiGrid2D(C.Structure):
         _fields_ = [("grids2D", C.POINTER(C.POINTER(Grid2D))), ("numGrids", C.c_int), ("maxGrids", C.c_int),
-                    ("matrixA", ct * 4), ("sizeA", C.c_int), ("alfa", C.c_int), ("ctx", C.c_void_p), ("fuse", C.c_int)]
+                    ("matrixA", ct * 4), ("sizeA", C.c_int), ("alfa", C.c_int), ("ctx", C.c_void_p), ("fuse", C.c_int),
+                    ("smoother", C.c_int), ("omega", ct)]
 
     return Grid2D, MultiGrid2D
 
@@ -343,6 +360,12 @@ class _MGBase:
     @property
     def maxGrids(self):
         return self._mg.contents.maxGrids
+
+    def set_smoother(self, name, omega=None):
+        """'rbgs' = red-black Gauss-Seidel (the reference's smoother), 'jacobi' = weighted Jacobi (addition)"""
+        self._mg.contents.smoother = {"rbgs": 0, "jacobi": 1}[name]
+        if omega is not None:
+            self._mg.contents.omega = float(omega)
 
     def VCycle(self, gridID, v1, v2):
         self._call("VCycle", C.c_int(gridID), C.c_int(v1), C.c_int(v2))
@@ -403,6 +426,12 @@ class MultiGrid3D(_MGBase):
     def InitF(self, gridID):
         self._call("InitF", C.c_int(gridID))
 
+    def DiffStats(self, gridID=0):
+        """(mean |diff|, max |diff|, relative L2) of diff = analytic - v  (Grid3D::PrintDiff as numbers)"""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._call("DiffStats", C.c_int(gridID), C.byref(a), C.byref(b), C.byref(c))
+        return float(a.value), float(b.value), float(c.value)
+
     def setToValue_v(self, gridID, value, modifyBoundaries):
         g = self.grid(gridID)
         self._call("setToValue", C.c_void_p(g.d_v), _ip(g.sizeXYZ), self._ct(value), C.c_int(int(modifyBoundaries)))
@@ -453,6 +482,11 @@ class MultiGrid2D(_MGBase):
 
     def grid(self, gridID):
         return self._mg.contents.grids2D[gridID].contents
+
+    def MeanAbsoluteError(self, gridID=0):
+        out = C.c_double()
+        self._call("MeanAbsoluteError", C.c_int(gridID), C.byref(out))
+        return float(out.value)
 
     def size(self, gridID):
         return tuple(self.grid(gridID).sizeXY)

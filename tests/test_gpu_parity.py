@@ -301,3 +301,71 @@ def test_norm2_wave_reduction(ctx):
         x = rng.uniform(-1, 1, cnt)
         got = P.ops3d.norm2(ctx, x)
         assert abs(got - float(np.dot(x, x))) <= 1e-12 * cnt
+
+
+# ------------------------------------------------------------------ additions without a reference counterpart
+@pytest.mark.parametrize("layout", ["natural", "xsplit"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_weighted_jacobi_3d_vs_oracle(ctx, layout, dtype):
+    """weighted Jacobi is named by north_star but absent from the reference: parity unpinned; the HIP kernel must
+    equal the oracle's restatement of the same expression bit for bit"""
+    ops = OPS3[layout]
+    n3, rg = (33, 17, 9), [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(9)
+    v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    om = float(dtype(2) / dtype(3))
+    for k in (1, 2, 5):
+        assert bits_equal(ops.jacobi(ctx, v, f, n3, rg, om, k), O.jacobi3d(n3, rg, v, f, om, k, dtype=dtype))
+
+
+def test_weighted_jacobi_2d_vs_oracle(ctx):
+    n2, rg = (65, 17), [0, 20, -3, 20]
+    rng = np.random.default_rng(10)
+    for dtype in (np.float32, np.float64):
+        v = rng.uniform(-1, 1, O.shape(n2)).astype(dtype)
+        f = rng.uniform(-1, 1, O.shape(n2)).astype(dtype)
+        om = float(dtype(0.8))
+        for k in (1, 4):
+            assert bits_equal(P.ops2d.jacobi(ctx, v, f, n2, rg, A2, 2, om, k), O.jacobi2d(n2, rg, A2, 2, v, f, om, k, dtype=dtype))
+
+
+def test_jacobi_vcycle_converges_and_diff_stats(ctx):
+    """V-cycles with the weighted-Jacobi smoother (CORRECT residual) reduce the error like multigrid should, and
+    DiffStats (Grid3D::PrintDiff as a device reduction) agrees with numpy on the downloaded field"""
+    n = 65
+    mg = P.MultiGrid3D(ctx, [n] * 3, R3, np.float64, residual_mode=P.CORRECT)
+    mg.set_smoother("jacobi", 6.0 / 7.0)
+    errs = []
+    for _ in range(6):
+        mg.VCycle(0, 3, 3)
+        errs.append(mg.DiffStats(0)[2])
+    assert errs[-1] < 2e-3 and errs[-1] < errs[0]
+    v = mg.download_v(0)
+    t = np.float64
+    x = np.array([t(t(0) + i * (t(1) / t(n - 1))) for i in range(n)])
+    s = np.sin(np.pi * x)
+    u = s[None, None, :] * s[None, :, None] * s[:, None, None]
+    d = u - v
+    mean_abs, max_abs, rel_l2 = mg.DiffStats(0)
+    assert abs(mean_abs - np.abs(d).mean()) <= 1e-12
+    assert abs(max_abs - np.abs(d).max()) <= 1e-12
+    assert abs(rel_l2 - np.linalg.norm(d.ravel()) / np.linalg.norm(u.ravel())) <= 1e-10
+    mg.close()
+
+
+def test_2d_mean_absolute_error_metric(ctx):
+    """the thesis' accuracy metric (Fig. 4.3; PrintMeanAbsoluteError, C2/Grid2D.cu:123-154) on the device"""
+    n = 129
+    mg = P.MultiGrid2D(ctx, [n] * 2, [0, 20, 0, 20], A2, 2, np.float32)
+    mg.FullMultiGridVCycle(0, 1, 100, 100)
+    v = mg.download_v(0)
+    f32 = np.float32
+    hx = f32(20) / f32(n - 1)
+    xs = np.array([f32(f32(0) + f32(i) * hx) for i in range(n)], f32)
+    X, Y = xs[None, :], xs[:, None]
+    real = (f32(2) * X * X - f32(4) * X * Y + f32(2) * Y * Y).astype(f32)
+    want = np.abs((v - real)[1:-1, 1:-1].astype(np.float64)).mean()
+    got = mg.MeanAbsoluteError(0)
+    assert abs(got - want) <= 1e-6 * max(1.0, want)
+    mg.close()
