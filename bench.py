@@ -120,11 +120,14 @@ def main():
     reset()
     e0, e1 = ctx.event(), ctx.event()
     if world == 1:
-        mg.Relax(0, 2)
+        # the smoother exactly as the cycle calls it: Relax(grid, v1) = v1 red-black sweeps per call
+        mg.Relax(0, args.v1)
         ctx.sync()
         ctx.record(e0)
-        mg.Relax(0, args.smoother_sweeps)
+        for _ in range(args.smoother_sweeps // max(args.v1, 1)):
+            mg.Relax(0, args.v1)
         ctx.record(e1)
+        args.smoother_sweeps = (args.smoother_sweeps // max(args.v1, 1)) * max(args.v1, 1)
         my_lups_per_launch = (n - 2) ** 3 / 2.0
         kname = "relax3d_xs_kernel<%s> (finest level, x-split layout, one colour per launch)"
     else:

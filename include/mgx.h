@@ -81,7 +81,8 @@ int mgx_ctx_sync(mgx_ctx* ctx);                 /* waits for the compute and com
 int mgx_ctx_device(const mgx_ctx* ctx, int* device);
 /* tuning knobs of the x-split smoother kernel (speed only, never results): "relax3d.ty" waves
  * per block and "relax3d.rows" consecutive rows per lane, each in {1,2,4,8}; "relax3d.zchunk"
- * planes per block (0 = automatic); "relax3d.xcd" 0/1/2 block-to-tile mapping (2 = every XCD owns a y-slab and walks z) */
+ * planes per block (0 = automatic); "relax3d.xcd" 0/1/2 block-to-tile mapping (2 = every XCD owns a y-slab and walks z);
+ * "relax3d.wave_planes" slab height of the time-skewed pass order (< 0 automatic, 0 = whole-grid passes) */
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value);
 /* raw hipStream_t of the compute stream (for callers that bring their own HIP code) */
 int mgx_ctx_stream(const mgx_ctx* ctx, void** hip_stream);

@@ -558,10 +558,31 @@ static void relax3d_xs_pass(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
     }
 }
 
+// `ncycles` red-black sweeps = 2*ncycles colour passes.  On large levels the passes are time-skewed over
+// z-slabs ("wavefront" order): slab by slab, pass s runs on the planes [a-s, a+B-s) right after pass s-1 ran
+// on [a-s+1, a+B-s+1).  Pass s at plane z needs pass s-1 only at planes z-1, z, z+1, so every point still sees
+// exactly the values it would see with whole-grid passes (bit-identical result), but a slab's v and f
+// (B planes, sized to sit in the 256 MiB Infinity Cache) are re-used by all passes before they leave the
+// chip: HBM sees about one read of v and f and one write of v per call instead of one per sweep.
 template <class real>
 static int relax3d_xsplit(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int ncycles) {
-    for (int k = 0; k < ncycles; k++)
-        for (int colour = 0; colour < 2; colour++) relax3d_xs_pass<real>(ctx, v, f, n[0], n[1], 1, n[2] - 1, hx2, hy2, hz2, colour);
+    const int npass = 2 * ncycles, zb = 1, ze = n[2] - 1;
+    const size_t plane_bytes = (size_t)n[0] * n[1] * sizeof(real);
+    int B = ctx->relax_wave_planes;
+    if (B < 0) {  // automatic: v + f of a slab (plus the skew margin) in about 64 MiB
+        B = (int)((64u << 20) / (2 * plane_bytes));
+        if (B * 4 > ze - zb || B < 2 * npass) B = 0;  // small level, or slabs thinner than the skew: whole-grid passes
+    }
+    if (B <= 0 || npass < 2) {
+        for (int s = 0; s < npass; s++) relax3d_xs_pass<real>(ctx, v, f, n[0], n[1], zb, ze, hx2, hy2, hz2, s & 1);
+        return MGX_OK;
+    }
+    for (int a = zb; a < ze + npass - 1; a += B)
+        for (int s = 0; s < npass; s++) {
+            const int lo = a - s > zb ? a - s : zb;
+            const int hi = a + B - s < ze ? a + B - s : ze;
+            if (hi > lo) relax3d_xs_pass<real>(ctx, v, f, n[0], n[1], lo, hi, hx2, hy2, hz2, s & 1);
+        }
     return MGX_OK;
 }
 
@@ -912,6 +933,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "relax3d.ty")) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.ty (waves per block) must be 1, 2, 4 or 8");
         ctx->relax_ty = value;
+    } else if (!strcmp(name, "relax3d.wave_planes")) {
+        ctx->relax_wave_planes = value;  // < 0 automatic, 0 off (whole-grid passes), > 0 planes per slab
     } else if (!strcmp(name, "relax3d.rows")) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.rows must be 1, 2, 4 or 8");
         ctx->relax_rows = value;

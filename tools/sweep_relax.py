@@ -21,7 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=513)
     ap.add_argument("--dtype", default="f64")
-    ap.add_argument("--sweeps", type=int, default=10)
+    ap.add_argument("--sweeps", type=int, default=2, help="sweeps per Relax call (V(2,2) calls Relax with 2)")
+    ap.add_argument("--calls", type=int, default=5, help="Relax calls per timing")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--configs", default="")
     args = ap.parse_args()
@@ -29,32 +30,33 @@ def main():
     w = np.dtype(dtype).itemsize
     ctx = P.Context(0)
     n = args.n
-    cfgs = [("natural", 4, 4, 0, 0)]
+    cfgs = [("natural", 4, 4, 0, 0, 0)]
     if args.configs:
         for c in args.configs.split(","):
-            ty, rows, zc, xcd = c.split(":")
-            cfgs.append(("xsplit", int(ty), int(rows), int(zc), int(xcd)))
+            ty, rows, zc, xcd, wp = c.split(":")
+            cfgs.append(("xsplit", int(ty), int(rows), int(zc), int(xcd), int(wp)))
     else:
-        for xcd in (2, 1):
-            for ty, rows in ((4, 2), (4, 1), (2, 4), (4, 4), (8, 2), (8, 1), (2, 2)):
-                for zc in (2, 4, 8, 16, 32):
-                    cfgs.append(("xsplit", ty, rows, zc, xcd))
+        for wp in (0, 6, 8, 12, 16, 24, 32, 48, 64):
+            for ty, rows, zc in ((4, 2, 4), (8, 1, 8), (4, 1, 4)):
+                cfgs.append(("xsplit", ty, rows, zc, 1, wp))
     mgs = {lay: P.MultiGrid3D(ctx, [n] * 3, [0, 1, 0, 1, 0, 1], dtype, nlevels=1, layout=lay) for lay in ("natural", "xsplit")}
     e0, e1 = ctx.event(), ctx.event()
     times = {c: [] for c in cfgs}
     for r in range(args.rounds + 1):
         for c in cfgs:
-            lay, ty, rows, zc, xcd = c
+            lay, ty, rows, zc, xcd, wp = c
             ctx.set_param("relax3d.ty", ty)
             ctx.set_param("relax3d.rows", rows)
+            ctx.set_param("relax3d.wave_planes", wp)
             ctx.set_param("relax3d.zchunk", zc)
             ctx.set_param("relax3d.xcd", xcd)
             mg = mgs[lay]
             ctx.sync()
             ctx.record(e0)
-            mg.Relax(0, args.sweeps)
+            for _ in range(args.calls):
+                mg.Relax(0, args.sweeps)
             ctx.record(e1)
-            ms = ctx.elapsed_ms(e0, e1) / args.sweeps
+            ms = ctx.elapsed_ms(e0, e1) / (args.sweeps * args.calls)
             if r > 0:
                 times[c].append(ms)
     lups = (n - 2) ** 3
@@ -63,7 +65,7 @@ def main():
         t = np.array(times[c])
         med, mn = float(np.median(t)), float(t.min())
         gbs = 3 * w * lups / (med * 1e-3) / 1e9
-        out.append(dict(layout=c[0], ty=c[1], rows=c[2], zchunk=c[3], xcd=c[4], ms_median=round(med, 4), ms_min=round(mn, 4),
+        out.append(dict(layout=c[0], ty=c[1], rows=c[2], zchunk=c[3], xcd=c[4], wave_planes=c[5], ms_median=round(med, 4), ms_min=round(mn, 4),
                          mlups=round(lups / (med * 1e-3) / 1e6, 1), alg_GBps=round(gbs, 1), frac_hbm=round(gbs / 8000.0, 4)))
     out.sort(key=lambda r: r["ms_median"])
     for r in out:
