@@ -70,7 +70,9 @@ __global__ void __launch_bounds__(256) relax3d_colour_kernel(real* __restrict__ 
 // hit in L1/L2, R stores.  All R rows' loads are issued before the first use, which keeps
 // R x 16 bytes of HBM traffic in flight per lane.  vin and vout alias the same array; the entries
 // read and the entries written are disjoint by colour, which is what makes __restrict__ legitimate.
-template <class real, int TYW, int R>
+// ABL != 0 builds diagnostic variants for tools/sweep_relax.py ("relax3d.ablate"; results are WRONG):
+// 1 = no f load, 2 = no store (one lane keeps the value alive), 4 = no side / edge-row loads, 8 = no division.
+template <class real, int TYW, int R, int ABL = 0>
 __global__ void __launch_bounds__(64 * TYW)
     relax3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                       int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
@@ -137,11 +139,11 @@ __global__ void __launch_bounds__(64 * TYW)
             const int qr = q ^ (r & 1);
             const int hq = qr * H, ho = (1 - qr) * H;
             U[r] = vin[rowb[r] + sxy + hq + j];
-            side[r] = vin[rowb[r] + ho + j + (qr ? 1 : -1) + (qr | j ? 0 : H)];
-            fv[r] = f[rowb[r] + hq + j];
+            side[r] = (ABL & 4) ? c_cur[r] : vin[rowb[r] + ho + j + (qr ? 1 : -1) + (qr | j ? 0 : H)];
+            fv[r] = (ABL & 1) ? (real)1 : f[rowb[r] + hq + j];
         }
-        const real Nedge = vin[rowb[0] - sx + q * H + j];
-        const real Sedge = vin[rowb[R - 1] + sx + (q ^ ((R - 1) & 1)) * H + j];
+        const real Nedge = (ABL & 4) ? c_cur[0] : vin[rowb[0] - sx + q * H + j];
+        const real Sedge = (ABL & 4) ? c_cur[R - 1] : vin[rowb[R - 1] + sx + (q ^ ((R - 1) & 1)) * H + j];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int qr = q ^ (r & 1);
@@ -149,8 +151,11 @@ __global__ void __launch_bounds__(64 * TYW)
             const real E = qr ? side[r] : c_cur[r];
             const real N = r == 0 ? Nedge : c_cur[r - 1];
             const real S = r == R - 1 ? Sedge : c_cur[r + 1];
-            const real out = relax3d_point<real>(W, E, N, S, c_prev[r], U[r], fv[r], hx2, hy2, hz2);
-            if ((qr | j) && r < nrows) vout[rowb[r] + qr * H + j] = out;  // x = 2j+q_r >= 1
+            real out = relax3d_point<real>(W, E, N, S, c_prev[r], U[r], fv[r], hx2, hy2, hz2);
+            if (ABL & 8) out = (W + E + N + S + c_prev[r] + U[r] - fv[r]) * hx2;
+            if (ABL & 2) {
+                if (out == (real)123456.789) vout[rowb[r] + qr * H + j] = out;
+            } else if ((qr | j) && r < nrows) vout[rowb[r] + qr * H + j] = out;  // x = 2j+q_r >= 1
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -522,6 +527,18 @@ static void launch_xs(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int 
     const int H = (sx + 1) / 2;
     const int gx = ceil_div(H - 1, 64), gy = ceil_div(sy - 2, TYW * R), gz = ceil_div(zend - zbeg, zchunk);
     const unsigned nblocks = ctx->relax_xcd == 2 ? 8u * ((gx * gy + 7) / 8) * gz : (unsigned)gx * gy * gz;
+    if (TYW == 4 && R == 2 && ctx->relax_ablate) {  // diagnostics only
+#define MGX_ABL(A)                                                                                                   \
+    case A:                                                                                                          \
+        hipLaunchKernelGGL((relax3d_xs_kernel<real, 4, 2, A>), dim3(nblocks), dim3(64, 4, 1), 0, ctx->compute,       \
+                           (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd); \
+        return;
+        switch (ctx->relax_ablate) {
+            MGX_ABL(1) MGX_ABL(2) MGX_ABL(3) MGX_ABL(4) MGX_ABL(5) MGX_ABL(7) MGX_ABL(8) MGX_ABL(12) MGX_ABL(15)
+            default: break;
+        }
+#undef MGX_ABL
+    }
     hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
                        (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
 }
@@ -933,6 +950,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "relax3d.ty")) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.ty (waves per block) must be 1, 2, 4 or 8");
         ctx->relax_ty = value;
+    } else if (!strcmp(name, "relax3d.ablate")) {
+        ctx->relax_ablate = value;  // diagnostics: non-zero gives WRONG results (see relax3d_xs_kernel)
     } else if (!strcmp(name, "relax3d.wave_planes")) {
         ctx->relax_wave_planes = value;  // < 0 automatic, 0 off (whole-grid passes), > 0 planes per slab
     } else if (!strcmp(name, "relax3d.rows")) {
