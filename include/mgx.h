@@ -124,11 +124,13 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
  * mgx2d_mean_abs_error: mean over the interior of |v - (2x^2-4xy+2y^2)| -- the accuracy metric of the thesis
  *   (PrintMeanAbsoluteError, CUDA_TESI/CUDA Lyapunov 2D/Grid2D.cu:123-154), reduced on the device.
  * mgx3dxs_*: the same operators on the device-internal "x-split" layout
- *   idx = (x>>1) + (x&1)*((sx+1)/2) + y*sx + z*sx*sy
- *   (every x-row stored as its even-x half followed by its odd-x half; rows and planes in the
- *   reference order).  In row (y,z) the points of one colour are one contiguous half-row, so a
- *   red+black sweep moves the algorithmic minimum of 3 reals per point through HBM.  Results are
- *   bit-identical to the natural-layout operators; mgx3dxs_pack / _unpack convert (out of place).
+ *   idx = (x>>1) + (x&1)*H + y*P + z*P*sy,  H = roundup((sx+1)/2, A), P = H + roundup(sx/2, A),
+ *   A = 128/sizeof(real) elements
+ *   (every x-row stored as its even-x half followed by its odd-x half, both starting on a 128-byte
+ *   boundary; rows and planes in the reference order).  In row (y,z) the points of one colour are one
+ *   contiguous, line-aligned half-row, so a red+black sweep moves the algorithmic minimum of 3 reals per
+ *   point through HBM in full cache lines.  Results are bit-identical to the natural-layout operators;
+ *   mgx3dxs_pack / _unpack convert (out of place); array sizes: mgx3dxs_elems.
  * mgx_norm2: sum of squares of `count` reals in double (wave-wide shuffle reduction +
  *   one atomic per block); host result, blocking.  An addition: the reference has no norm.
  */
@@ -154,7 +156,11 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                            const real h[3], real omega, int ncycles);                                   \
     int mgx3d_diff_stats_##SFX(mgx_ctx* ctx, const real* v, const int n[3], const double* host_tx,      \
                                const double* host_ty, const double* host_tz, double host_out[4]);       \
-    /* x-split twins: same operators on arrays whose x-rows are de-interleaved (see below) */           \
+    /* x-split twins: same operators on arrays whose x-rows are de-interleaved (see below).  An        */ \
+    /* x-split array of an (sx, sy, sz) grid has mgx3dxs_elems elements (rows are padded to cache      */ \
+    /* lines), one z-plane has mgx3dxs_plane_elems; pad entries must be zero (mgx_memset_zero once).   */ \
+    size_t mgx3dxs_elems_##SFX(const int n[3]);                                                         \
+    size_t mgx3dxs_plane_elems_##SFX(int sx, int sy);                                                   \
     int mgx3dxs_pack_##SFX(mgx_ctx* ctx, const real* natural, real* xsplit, const int n[3]);            \
     int mgx3dxs_unpack_##SFX(mgx_ctx* ctx, const real* xsplit, real* natural, const int n[3]);          \
     int mgx3dxs_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3],      \

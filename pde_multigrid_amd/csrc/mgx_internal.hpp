@@ -19,6 +19,7 @@ struct mgx_ctx {
     int relax_xcd = 1;     // XCD-aware block -> tile mapping
     int relax_rows = 2;    // consecutive rows per lane (register blocking in y) of relax3d_xs_kernel
     int relax_wave_planes = -1;  // time-skewed slab height of relax3d_xsplit: <0 automatic, 0 off
+    int relax_shfl = 1;    // side neighbour by wave shuffle instead of a load
     int relax_ablate = 0;  // diagnostic kernel variants (tools only)
     int rr_pzchunk = 0;    // coarse planes per block of residual_restrict3d_kernel, 0 = automatic
     void* scratch = nullptr;  // small device workspace (reductions, tables)

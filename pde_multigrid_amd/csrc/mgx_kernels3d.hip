@@ -72,12 +72,16 @@ __global__ void __launch_bounds__(256) relax3d_colour_kernel(real* __restrict__ 
 // read and the entries written are disjoint by colour, which is what makes __restrict__ legitimate.
 // ABL != 0 builds diagnostic variants for tools/sweep_relax.py ("relax3d.ablate"; results are WRONG):
 // 1 = no f load, 2 = no store (one lane keeps the value alive), 4 = no side / edge-row loads, 8 = no division.
-template <class real, int TYW, int R, int ABL = 0>
+// SHFL: the side value of a lane is the "own" value of the neighbouring lane, so it is taken with a wave
+// shuffle instead of a second (L1/L2-hit) load; only the wave's edge lane still loads it.
+template <class real, int TYW, int R, int ABL = 0, bool SHFL = true>
 __global__ void __launch_bounds__(64 * TYW)
     relax3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                       int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
                       int xcd_mode) {
-    const int H = (sx + 1) >> 1;
+    const Geo<XSplit, real> g(sx, sy);
+    const int H = g.H;
+    const int M = (sx + 1) >> 1;  // entries of the even-x half (the odd-x half has M-1)
     // 1-D grid decoded to (bx, by, bz).  Workgroups are dealt round-robin over the 8 XCDs
     // (MI355X_MICROARCH.md: blocks b and b+8 share an XCD, each XCD has its own 4 MiB L2).
     //   xcd_mode 0: plain order, x fastest, then y tiles, then z-chunks
@@ -107,7 +111,7 @@ __global__ void __launch_bounds__(64 * TYW)
     const int j = bx * 64 + threadIdx.x;
     // one wave per row group: y (hence the colour parity q and every row offset) is wave-uniform -> SGPRs
     const int y0 = 1 + (by * TYW + __builtin_amdgcn_readfirstlane(threadIdx.y)) * R;
-    if (y0 >= sy - 1 || j >= H - 1) return;  // x = 2j+q <= sx-2 needs j <= H-2
+    if (y0 >= sy - 1 || j >= M - 1) return;  // x = 2j+q <= sx-2 needs j <= M-2
     const int nrows = min(R, sy - 1 - y0);    // rows y0 .. y0+nrows-1 are interior
     // planes [zbeg, zend) of the local array are updated (1 .. sz-2 for a whole grid; the owned planes of
     // a z-slab, whose neighbours below / above are ghost planes); `colour` already includes the parity of
@@ -115,13 +119,14 @@ __global__ void __launch_bounds__(64 * TYW)
     const int z0 = zbeg + bz * zchunk;
     const int z1 = min(z0 + zchunk, zend);
     if (z0 >= z1) return;
-    const size_t sxy = (size_t)sx * sy;
+    const size_t sxy = g.PL;
+    const int P = g.P;
     // row bases at plane z0.  Row y0+nrows may be the boundary row sy-1: it is loaded like any other row
     // because its "own" value is the S neighbour of the last interior row; rows past sy-1 are clamped
     // onto it (loads stay valid, nothing is stored for r >= nrows)
     size_t rowb[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) rowb[r] = (size_t)min(y0 + r, sy - 1) * sx + (size_t)z0 * sxy;
+    for (int r = 0; r < R; r++) rowb[r] = g.row(min(y0 + r, sy - 1), z0);
     int q = (colour + y0 + z0) & 1;  // parity of row r is q ^ (r & 1)
     real c_prev[R], c_cur[R];
 #pragma unroll
@@ -133,17 +138,27 @@ __global__ void __launch_bounds__(64 * TYW)
     for (int z = z0; z < z1; z++) {
         real U[R], side[R], fv[R];
         // lane j = 0 with q_r = 0 (x = 0, a boundary point that is never written) would read index -1:
-        // it reads index H-1 of half 0 instead and the result is discarded
+        // it reads index M-1 of half 0 instead and the result is discarded
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int qr = q ^ (r & 1);
             const int hq = qr * H, ho = (1 - qr) * H;
             U[r] = vin[rowb[r] + sxy + hq + j];
-            side[r] = (ABL & 4) ? c_cur[r] : vin[rowb[r] + ho + j + (qr ? 1 : -1) + (qr | j ? 0 : H)];
+            if (ABL & 4) {
+                side[r] = c_cur[r];
+            } else if (SHFL) {
+                // neighbour lane: j+1 when q_r = 1, j-1 when q_r = 0 (q_r is wave-uniform).  The wave's edge lane,
+                // and the last active lane (its neighbour j+1 = M-1 holds the boundary entry but has exited), load.
+                const real nb = qr ? __shfl_down(c_cur[r], 1, 64) : __shfl_up(c_cur[r], 1, 64);
+                const bool edge = qr ? (threadIdx.x == 63 || j == M - 2) : (threadIdx.x == 0);
+                side[r] = edge ? vin[rowb[r] + ho + j + (qr ? 1 : -1) + (qr | j ? 0 : M)] : nb;
+            } else {
+                side[r] = vin[rowb[r] + ho + j + (qr ? 1 : -1) + (qr | j ? 0 : M)];
+            }
             fv[r] = (ABL & 1) ? (real)1 : f[rowb[r] + hq + j];
         }
-        const real Nedge = (ABL & 4) ? c_cur[0] : vin[rowb[0] - sx + q * H + j];
-        const real Sedge = (ABL & 4) ? c_cur[R - 1] : vin[rowb[R - 1] + sx + (q ^ ((R - 1) & 1)) * H + j];
+        const real Nedge = (ABL & 4) ? c_cur[0] : vin[rowb[0] - P + q * H + j];
+        const real Sedge = (ABL & 4) ? c_cur[R - 1] : vin[rowb[R - 1] + P + (q ^ ((R - 1) & 1)) * H + j];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int qr = q ^ (r & 1);
@@ -180,16 +195,17 @@ __global__ void __launch_bounds__(256) jacobi3d_kernel(const real* __restrict__ 
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int z = blockIdx.z;
     if (x >= sx || y >= sy) return;
-    const int H = (sx + 1) >> 1;
-    const size_t sxy = (size_t)sx * sy;
-    const size_t row = (size_t)y * sx + (size_t)z * sxy;
+    const Geo<L, real> g(sx, sy);
+    const int H = g.H, P = g.P;
+    const size_t sxy = g.PL;
+    const size_t row = g.row(y, z);
     const size_t i = row + L::pos(x, H);
     const real c = v[i];
     if (x == 0 || x == sx - 1 || y == 0 || y == sy - 1 || z == 0 || z == sz - 1) {
         vout[i] = c;
         return;
     }
-    const real u = relax3d_point<real>(v[row + L::pos(x - 1, H)], v[row + L::pos(x + 1, H)], v[i - sx], v[i + sx], v[i - sxy],
+    const real u = relax3d_point<real>(v[row + L::pos(x - 1, H)], v[row + L::pos(x + 1, H)], v[i - P], v[i + P], v[i - sxy],
                                        v[i + sxy], f[i], hx2, hy2, hz2);
     vout[i] = c + omega * (u - c);
 }
@@ -203,12 +219,12 @@ template <class real, class L>
 __global__ void __launch_bounds__(256) diff_stats3d_kernel(const real* __restrict__ v, int sx, int sy, int sz,
                                                            const double* __restrict__ tx, const double* __restrict__ ty,
                                                            const double* __restrict__ tz, double* __restrict__ out) {
-    const int H = (sx + 1) >> 1;
+    const Geo<L, real> g(sx, sy);
     const int y = blockIdx.y, z = blockIdx.z;
     double s1 = 0, mx = 0, s2 = 0, sr = 0;
     for (int x = threadIdx.x; x < sx; x += blockDim.x) {
         const real realSol = (real)(tx[x] * ty[y] * tz[z]);
-        const real diff = realSol - v[(size_t)y * sx + (size_t)z * sx * sy + L::pos(x, H)];
+        const real diff = realSol - v[g.row(y, z) + g.pos(x)];
         const double a = fabs((double)diff);
         s1 += a;
         mx = a > mx ? a : mx;
@@ -246,15 +262,16 @@ __global__ void __launch_bounds__(256) residual3d_kernel(const real* __restrict_
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int z = blockIdx.z;
     if (x >= sx || y >= sy) return;
-    const int H = (sx + 1) >> 1;
-    const size_t sxy = (size_t)sx * sy;
-    const size_t row = (size_t)y * sx + (size_t)z * sxy;
+    const Geo<L, real> g(sx, sy);
+    const int H = g.H, P = g.P;
+    const size_t sxy = g.PL;
+    const size_t row = g.row(y, z);
     const size_t i = row + L::pos(x, H);
     if (x == 0 || x == sx - 1 || y == 0 || y == sy - 1 || z == 0 || z == sz - 1) {
         r[i] = (real)0;  // N3/MultiGrid3D.cpp:704-705
         return;
     }
-    r[i] = residual3d_point<real, MODE>(v[row + L::pos(x - 1, H)], v[row + L::pos(x + 1, H)], v[i - sx], v[i + sx],
+    r[i] = residual3d_point<real, MODE>(v[row + L::pos(x - 1, H)], v[row + L::pos(x + 1, H)], v[i - P], v[i + P],
                                         v[i - sxy], v[i + sxy], v[i], f[i], hx2, hy2, hz2);
 }
 
@@ -266,16 +283,16 @@ __global__ void __launch_bounds__(256) restrict3d_kernel(const real* __restrict_
     const int py = blockIdx.y * blockDim.y + threadIdx.y;
     const int pz = blockIdx.z;
     if (px >= cx || py >= cy) return;
-    const int FH = (fx + 1) >> 1, CH = (cx + 1) >> 1;
-    const size_t fxy = (size_t)fx * fy;
-    const size_t ci = L::pos(px, CH) + (size_t)py * cx + (size_t)pz * cx * cy;
-    const real* c = fine + ((size_t)(2 * py) * fx + (size_t)(2 * pz) * fxy);  // row base of the fine centre
+    const Geo<L, real> gf(fx, fy), gc(cx, cy);
+    const int FH = gf.H;
+    const size_t ci = gc.pos(px) + gc.row(py, pz);
+    const real* c = fine + gf.row(2 * py, 2 * pz);  // row base of the fine centre
     const int gx = 2 * px;
     if (px == 0 || px == cx - 1 || py == 0 || py == cy - 1 || pz == 0 || pz == cz - 1) {
         coarse[ci] = c[L::pos(gx, FH)];  // injection, N3/MultiGrid3D.cpp:113-119
         return;
     }
-    const ptrdiff_t sy_ = fx, sz_ = (ptrdiff_t)fxy;
+    const ptrdiff_t sy_ = gf.P, sz_ = (ptrdiff_t)gf.PL;
     coarse[ci] = restrict3d_point<real>([&](int dx, int dy, int dz) { return c[L::pos(gx + dx, FH) + dy * sy_ + dz * sz_]; });
 }
 
@@ -290,13 +307,14 @@ __global__ void __launch_bounds__(256) interpolate3d_kernel(real* __restrict__ f
     const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int z = 1 + blockIdx.z;
     if (x >= fx - 1 || y >= fy - 1 || z >= fz - 1) return;
-    const int FH = (fx + 1) >> 1, CH = (cx + 1) >> 1;
-    const size_t cxy = (size_t)cx * cy;
-    const size_t fi = L::pos(x, FH) + (size_t)y * fx + (size_t)z * fx * fy;
-    const real* c = coarse + ((size_t)(y >> 1) * cx + (size_t)(z >> 1) * cxy);
+    const Geo<L, real> gf(fx, fy), gc(cx, cy);
+    const int CH = gc.H;
+    const size_t cxy = gc.PL;
+    const size_t fi = gf.pos(x) + gf.row(y, z);
+    const real* c = coarse + gc.row(y >> 1, z >> 1);
     const int gx = x >> 1;
     const real e = interpolate3d_point<real>(
-        x & 1, y & 1, z & 1, [&](int dx, int dy, int dz) { return c[L::pos(gx + dx, CH) + (size_t)dy * cx + (size_t)dz * cxy]; });
+        x & 1, y & 1, z & 1, [&](int dx, int dy, int dz) { return c[L::pos(gx + dx, CH) + (size_t)dy * gc.P + (size_t)dz * cxy]; });
     if (ADD) fine[fi] = fine[fi] + e;  // N3/MultiGrid3D.cpp:672
     else fine[fi] = e;
 }
@@ -312,12 +330,13 @@ template <class real, bool ADD>
 __global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict__ fine, int fx, int fy, int fzoff,
                                                                const real* __restrict__ coarse, int cx, int cy, int czoff,
                                                                int pzbeg) {
-    const int FH = (fx + 1) >> 1, CH = (cx + 1) >> 1;
+    const Geo<XSplit, real> gf(fx, fy), gc(cx, cy);
+    const int FH = gf.H, CH = gc.H;
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int py = blockIdx.y * blockDim.y + threadIdx.y;
     const int pz = pzbeg + blockIdx.z;
-    if (i >= FH - 1 || py >= cy - 1) return;  // fine x = 2i+1 <= fx-2, fine y = 2py+1 <= fy-2
-    const size_t cxy = (size_t)cx * cy, fxy = (size_t)fx * fy;
+    if (i >= ((fx + 1) >> 1) - 1 || py >= cy - 1) return;  // fine x = 2i+1 <= fx-2, fine y = 2py+1 <= fy-2
+    const size_t cxy = gc.PL, fxy = gf.PL;
     real c[2][2][2];
 #pragma unroll
     for (int dz = 0; dz < 2; dz++)
@@ -325,7 +344,7 @@ __global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict_
         for (int dy = 0; dy < 2; dy++)
 #pragma unroll
             for (int dx = 0; dx < 2; dx++)
-                c[dx][dy][dz] = coarse[XSplit::pos(i + dx, CH) + (size_t)(py + dy) * cx + (size_t)(pz + dz - czoff) * cxy];
+                c[dx][dy][dz] = coarse[XSplit::pos(i + dx, CH) + (size_t)(py + dy) * gc.P + (size_t)(pz + dz - czoff) * cxy];
     auto get = [&](int dx, int dy, int dz) { return c[dx][dy][dz]; };
 #pragma unroll
     for (int dz = 0; dz < 2; dz++) {
@@ -335,7 +354,7 @@ __global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict_
         for (int dy = 0; dy < 2; dy++) {
             const int y = 2 * py + dy;
             if (y < 1) continue;
-            const size_t row = (size_t)y * fx + (size_t)(z - fzoff) * fxy;
+            const size_t row = (size_t)y * gf.P + (size_t)(z - fzoff) * fxy;
             const real e0 = interpolate3d_point<real>(0, dy, dz, get);
             const real e1 = interpolate3d_point<real>(1, dy, dz, get);
             if (i >= 1) fine[row + i] = ADD ? fine[row + i] + e0 : e0;   // x = 2i
@@ -351,7 +370,8 @@ __global__ void __launch_bounds__(256) correct3d_kernel(real* __restrict__ fine,
     const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int z = 1 + blockIdx.z;
     if (x >= sx - 1 || y >= sy - 1 || z >= sz - 1) return;
-    const size_t i = L::pos(x, (sx + 1) >> 1) + (size_t)y * sx + (size_t)z * sx * sy;
+    const Geo<L, real> g(sx, sy);
+    const size_t i = g.pos(x) + g.row(y, z);
     fine[i] = fine[i] + err[i];
 }
 
@@ -361,7 +381,8 @@ __global__ void __launch_bounds__(256) set3d_kernel(real* __restrict__ g, int sx
     const int y = lo + blockIdx.y * blockDim.y + threadIdx.y;
     const int z = lo + blockIdx.z;
     if (x >= sx - lo || y >= sy - lo || z >= sz - lo) return;
-    g[L::pos(x, (sx + 1) >> 1) + (size_t)y * sx + (size_t)z * sx * sy] = value;
+    const Geo<L, real> ge(sx, sy);
+    g[ge.pos(x) + ge.row(y, z)] = value;
 }
 
 // f = (real)(((c * tx[x]) * ty[y]) * tz[z]) in double: Grid3D::InitF's left-to-right product
@@ -374,7 +395,8 @@ __global__ void __launch_bounds__(256) init_f3d_kernel(real* __restrict__ f, int
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int z = blockIdx.z;
     if (x >= sx || y >= sy) return;
-    f[L::pos(x, (sx + 1) >> 1) + (size_t)y * sx + (size_t)z * sx * sy] = (real)(c * tx[x] * ty[y] * tz[z]);
+    const Geo<L, real> g(sx, sy);
+    f[g.pos(x) + g.row(y, z)] = (real)(c * tx[x] * ty[y] * tz[z]);
 }
 
 // dst(layout LD) = src(layout LS), same sizes
@@ -384,9 +406,9 @@ __global__ void __launch_bounds__(256) relayout3d_kernel(const real* __restrict_
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int z = blockIdx.z;
     if (x >= sx || y >= sy) return;
-    const int H = (sx + 1) >> 1;
-    const size_t row = (size_t)y * sx + (size_t)z * sx * sy;
-    dst[row + LD::pos(x, H)] = src[row + LS::pos(x, H)];
+    const Geo<LS, real> gs(sx, sy);
+    const Geo<LD, real> gd(sx, sy);
+    dst[gd.row(y, z) + gd.pos(x)] = src[gs.row(y, z) + gs.pos(x)];
 }
 
 // ------------------------------------------------------------------ residual + restrict fused
@@ -409,8 +431,9 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
     const int px0 = blockIdx.x * CTX, py0 = blockIdx.y * CTY;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     const int nthreads = blockDim.x * blockDim.y;
-    const int H = (sx + 1) >> 1, CH = (cx + 1) >> 1;
-    const size_t sxy = (size_t)sx * sy;
+    const Geo<L, real> gf(sx, sy), gc(cx, cy);
+    const int H = gf.H, P = gf.P;
+    const size_t sxy = gf.PL;
     // fine window origin (may be -1 at the low edge: those entries are never read)
     const int gx0 = 2 * px0 - 1, gy0 = 2 * py0 - 1;
     // residual of fine plane gz into ring slot gz & 3.  The window is walked with a compile-time trip
@@ -428,12 +451,12 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
             const int gx = gx0 + lx, gy = gy0 + ly;
             in[k] = zin && t < FX * FY && gx >= 1 && gx < sx - 1 && gy >= 1 && gy < sy - 1;
             if (in[k]) {
-                const size_t row = (size_t)gy * sx + (size_t)(gz - fzoff) * sxy;
+                const size_t row = (size_t)gy * P + (size_t)(gz - fzoff) * sxy;
                 const size_t i = row + L::pos(gx, H);
                 O[k] = v[row + L::pos(gx - 1, H)];
                 E[k] = v[row + L::pos(gx + 1, H)];
-                N[k] = v[i - sx];
-                S[k] = v[i + sx];
+                N[k] = v[i - P];
+                S[k] = v[i + P];
                 D[k] = v[i - sxy];
                 U[k] = v[i + sxy];
                 C[k] = v[i];
@@ -462,7 +485,7 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
             const int ty = t / CTX, tx = t - ty * CTX;
             const int px = px0 + tx, py = py0 + ty;
             if (px >= cx || py >= cy) continue;
-            const size_t ci = L::pos(px, CH) + (size_t)py * cx + (size_t)(pz - czoff) * cx * cy;
+            const size_t ci = gc.pos(px) + gc.row(py, pz - czoff);
             if (px == 0 || px == cx - 1 || py == 0 || py == cy - 1 || !zinterior) {
                 coarse[ci] = (real)0;  // injection of a boundary residual, which is 0 (:704-705 then :113-119)
                 continue;
@@ -524,13 +547,13 @@ static int relax3d_natural(mgx_ctx* ctx, real* v, const real* f, const int n[3],
 template <class real, int TYW, int R>
 static void launch_xs(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
                       real hz2, int colour, int zchunk) {
-    const int H = (sx + 1) / 2;
-    const int gx = ceil_div(H - 1, 64), gy = ceil_div(sy - 2, TYW * R), gz = ceil_div(zend - zbeg, zchunk);
+    const int M = (sx + 1) / 2;
+    const int gx = ceil_div(M - 1, 64), gy = ceil_div(sy - 2, TYW * R), gz = ceil_div(zend - zbeg, zchunk);
     const unsigned nblocks = ctx->relax_xcd == 2 ? 8u * ((gx * gy + 7) / 8) * gz : (unsigned)gx * gy * gz;
     if (TYW == 4 && R == 2 && ctx->relax_ablate) {  // diagnostics only
 #define MGX_ABL(A)                                                                                                   \
     case A:                                                                                                          \
-        hipLaunchKernelGGL((relax3d_xs_kernel<real, 4, 2, A>), dim3(nblocks), dim3(64, 4, 1), 0, ctx->compute,       \
+        hipLaunchKernelGGL((relax3d_xs_kernel<real, 4, 2, A, false>), dim3(nblocks), dim3(64, 4, 1), 0, ctx->compute,       \
                            (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd); \
         return;
         switch (ctx->relax_ablate) {
@@ -539,8 +562,12 @@ static void launch_xs(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int 
         }
 #undef MGX_ABL
     }
-    hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
-                       (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
+    if (ctx->relax_shfl)
+        hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R, 0, true>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
+                           (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
+    else
+        hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R, 0, false>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
+                           (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
 }
 
 template <class real, int TYW>
@@ -822,7 +849,10 @@ int jacobi3d(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[3], co
         real* t = src; src = dst; dst = t;
     }
     MGX_LAUNCH_CHECK();
-    if (src != v) MGX_HIP(hipMemcpyAsync(v, src, sizeof(real) * (size_t)n[0] * n[1] * n[2], hipMemcpyDeviceToDevice, ctx->compute));
+    if (src != v) {
+        const Geo<L, real> g(n[0], n[1]);
+        MGX_HIP(hipMemcpyAsync(v, src, sizeof(real) * g.PL * (size_t)n[2], hipMemcpyDeviceToDevice, ctx->compute));
+    }
     return MGX_OK;
 }
 
@@ -912,6 +942,10 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
     }
 
 #define MGX_DEFINE_MISC3D(SFX, real)                                                                             \
+    size_t mgx3dxs_plane_elems_##SFX(int sx, int sy) { return mgx::Geo<mgx::XSplit, real>(sx, sy).PL; }          \
+    size_t mgx3dxs_elems_##SFX(const int n[3]) {                                                                 \
+        return n ? mgx::Geo<mgx::XSplit, real>(n[0], n[1]).PL * (size_t)n[2] : 0;                                \
+    }                                                                                                            \
     int mgx3dxs_relax_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, const real h[3],   \
                                         int colour, int zbeg, int zend, int zoff) {                              \
         return mgx::relax3d_colour_slab<real>(ctx, v, f, sx, sy, h, colour, zbeg, zend, zoff);                   \
@@ -950,6 +984,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "relax3d.ty")) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.ty (waves per block) must be 1, 2, 4 or 8");
         ctx->relax_ty = value;
+    } else if (!strcmp(name, "relax3d.shfl")) {
+        ctx->relax_shfl = value ? 1 : 0;
     } else if (!strcmp(name, "relax3d.ablate")) {
         ctx->relax_ablate = value;  // diagnostics: non-zero gives WRONG results (see relax3d_xs_kernel)
     } else if (!strcmp(name, "relax3d.wave_planes")) {

@@ -11,14 +11,37 @@
 
 namespace mgx {
 
-// Array layouts: position of column x inside its x-row (H = (sx+1)/2).
+// Array layouts.  pos(x, H) = position of column x inside its x-row; pitch / half give the row geometry.
 struct Natural {  // the reference layout: idx = x + y*sx + z*sx*sy   (N3/MultiGrid3D.cpp:531)
     static constexpr bool xsplit = false;
-    static __device__ __forceinline__ int pos(int x, int) { return x; }
+    static __host__ __device__ __forceinline__ int pos(int x, int) { return x; }
+    template <class real> static __host__ __device__ __forceinline__ int half(int sx) { return (sx + 1) >> 1; }
+    template <class real> static __host__ __device__ __forceinline__ int pitch(int sx) { return sx; }
 };
-struct XSplit {  // even-x half [0, H) then odd-x half [H, sx) of every row; rows/planes as in Natural
+// x-split: every row stores its even-x half at [0, (sx+1)/2) and its odd-x half at [H, H + sx/2); both halves
+// start on a 128-byte boundary (H and the row pitch are multiples of 128/sizeof(real) elements), so every
+// half-row -- the unit a colour pass streams -- begins on a cache line and full lines are written.
+// Rows and planes keep the reference order; pad entries are never read as data and stay zero.
+struct XSplit {
     static constexpr bool xsplit = true;
-    static __device__ __forceinline__ int pos(int x, int H) { return (x >> 1) + (x & 1) * H; }
+    static __host__ __device__ __forceinline__ int pos(int x, int H) { return (x >> 1) + (x & 1) * H; }
+    template <class real> static __host__ __device__ __forceinline__ int al() { return 128 / (int)sizeof(real); }
+    template <class real> static __host__ __device__ __forceinline__ int half(int sx) {
+        return (((sx + 1) >> 1) + al<real>() - 1) / al<real>() * al<real>();
+    }
+    template <class real> static __host__ __device__ __forceinline__ int pitch(int sx) {
+        return half<real>(sx) + ((sx >> 1) + al<real>() - 1) / al<real>() * al<real>();
+    }
+};
+
+// Row geometry of an (sx, sy, *) array in layout L: H = offset of the odd-x half, P = row pitch, PL = plane pitch.
+template <class L, class real>
+struct Geo {
+    int H, P;
+    size_t PL;
+    __host__ __device__ Geo(int sx, int sy) : H(L::template half<real>(sx)), P(L::template pitch<real>(sx)), PL((size_t)L::template pitch<real>(sx) * sy) {}
+    __host__ __device__ __forceinline__ size_t row(int y, int z) const { return (size_t)y * P + (size_t)z * PL; }
+    __host__ __device__ __forceinline__ int pos(int x) const { return L::pos(x, H); }
 };
 
 // MultiGrid3D::Relax per-point update.                      N3/MultiGrid3D.cpp:532 (=:561)

@@ -122,18 +122,32 @@ class Context:
 
 
 # --------------------------------------------------------------------------- raw operators
+def xs_geometry(sx, itemsize):
+    """(H, P): offset of the odd-x half and row pitch of the x-split layout (both multiples of a 128-byte line)"""
+    al = 128 // itemsize
+    H = ((sx + 1) // 2 + al - 1) // al * al
+    return H, H + (sx // 2 + al - 1) // al * al
+
+
 def xs_pack(a):
-    """numpy restatement of the x-split layout: every x-row as its even-x half then its odd-x half"""
+    """numpy restatement of the x-split layout: every x-row as its even-x half then, from the next 128-byte
+    boundary on, its odd-x half; rows padded to the pitch with zeros"""
     a = np.asarray(a)
-    return np.ascontiguousarray(np.concatenate([a[..., 0::2], a[..., 1::2]], axis=-1))
+    sx = a.shape[-1]
+    H, P = xs_geometry(sx, a.dtype.itemsize)
+    out = np.zeros(a.shape[:-1] + (P,), a.dtype)
+    out[..., :(sx + 1) // 2] = a[..., 0::2]
+    out[..., H:H + sx // 2] = a[..., 1::2]
+    return out
 
 
-def xs_unpack(a):
+def xs_unpack(a, sx):
     a = np.asarray(a)
-    H = (a.shape[-1] + 1) // 2
-    out = np.empty_like(a)
-    out[..., 0::2] = a[..., :H]
-    out[..., 1::2] = a[..., H:]
+    H, P = xs_geometry(sx, a.dtype.itemsize)
+    assert a.shape[-1] == P
+    out = np.empty(a.shape[:-1] + (sx,), a.dtype)
+    out[..., 0::2] = a[..., :(sx + 1) // 2]
+    out[..., 1::2] = a[..., H:H + sx // 2]
     return out
 
 
@@ -157,8 +171,10 @@ class _Ops:
         ptrs = [ctx.to_device(conv(np.ascontiguousarray(a, dtype=dtype))) if a is not None else None for a in arrays]
         try:
             check(call(*ptrs))
-            out = ctx.to_host(ptrs[out_index], out_shape, dtype)
-            return xs_unpack(out) if self.xsplit else out
+            if not self.xsplit:
+                return ctx.to_host(ptrs[out_index], out_shape, dtype)
+            P_ = xs_geometry(out_shape[-1], np.dtype(dtype).itemsize)[1]
+            return xs_unpack(ctx.to_host(ptrs[out_index], tuple(out_shape[:-1]) + (P_,), dtype), out_shape[-1])
         finally:
             for p in ptrs:
                 if p is not None:
@@ -195,24 +211,29 @@ class _Ops3D(_Ops):
         super().__init__(3, xsplit)
 
     def pack(self, ctx, a):
-        """device-side Natural -> XSplit conversion (mgx3dxs_pack), returned as stored"""
+        """device-side Natural -> XSplit conversion (mgx3dxs_pack), returned as stored (padded rows)"""
         s, _ = _ct(a.dtype)
         n = tuple(reversed(a.shape))
-        src, dst = ctx.to_device(a), ctx.malloc(a.nbytes)
+        fn = getattr(lib, "mgx3dxs_elems_" + s)
+        fn.restype = C.c_size_t
+        elems = fn(_ip(n))
+        P_ = xs_geometry(n[0], a.dtype.itemsize)[1]
+        assert elems == P_ * n[1] * n[2]
+        src, dst = ctx.to_device(a), ctx.to_device(np.zeros(elems, a.dtype))
         try:
             check(getattr(lib, "mgx3dxs_pack_" + s)(ctx._h, src, dst, _ip(n)))
-            return ctx.to_host(dst, a.shape, a.dtype)
+            return ctx.to_host(dst, a.shape[:-1] + (P_,), a.dtype)
         finally:
             ctx.free(src)
             ctx.free(dst)
 
-    def unpack(self, ctx, a):
+    def unpack(self, ctx, a, sx):
         s, _ = _ct(a.dtype)
-        n = tuple(reversed(a.shape))
-        src, dst = ctx.to_device(a), ctx.malloc(a.nbytes)
+        n = (sx,) + tuple(reversed(a.shape[:-1]))
+        src, dst = ctx.to_device(a), ctx.malloc(sx * a.shape[0] * a.shape[1] * a.dtype.itemsize)
         try:
             check(getattr(lib, "mgx3dxs_unpack_" + s)(ctx._h, src, dst, _ip(n)))
-            return ctx.to_host(dst, a.shape, a.dtype)
+            return ctx.to_host(dst, a.shape[:-1] + (sx,), a.dtype)
         finally:
             ctx.free(src)
             ctx.free(dst)

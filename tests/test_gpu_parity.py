@@ -105,7 +105,8 @@ def test_3d_xsplit_pack_unpack(ctx):
         for dtype in (np.float32, np.float64):
             a = rng.uniform(-1, 1, shape).astype(dtype)
             assert bits_equal(P.ops3d.pack(ctx, a), P.xs_pack(a))
-            assert bits_equal(P.ops3d.unpack(ctx, P.xs_pack(a)), a)
+            assert bits_equal(P.ops3d.unpack(ctx, P.xs_pack(a), shape[-1]), a)
+            assert bits_equal(P.xs_unpack(P.xs_pack(a), shape[-1]), a)
 
 
 @pytest.mark.parametrize("ty,rows,zchunk", [(1, 1, 1), (2, 2, 3), (4, 4, 0), (8, 1, 64), (4, 8, 7), (1, 8, 2), (2, 4, 5)])
@@ -122,6 +123,9 @@ def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, rows, zchun
         for xcd in (0, 1, 2):
             ctx.set_param("relax3d.xcd", xcd)
             assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 3), O.relax3d(n3, rg, v, f, 3, dtype=np.float64))
+        ctx.set_param("relax3d.shfl", 0)
+        assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 2), O.relax3d(n3, rg, v, f, 2, dtype=np.float64))
+        ctx.set_param("relax3d.shfl", 1)
         # time-skewed pass order over z-slabs of every height, including degenerate ones
         for wp in (1, 2, 3, 5, 8, 13, 39, 64):
             ctx.set_param("relax3d.wave_planes", wp)

@@ -30,21 +30,23 @@ def main():
     w = np.dtype(dtype).itemsize
     ctx = P.Context(0)
     n = args.n
-    cfgs = [("natural", 4, 4, 0, 0, 0)]
+    cfgs = [("natural", 4, 4, 0, 0, 0, 0)]
     if args.configs:
         for c in args.configs.split(","):
-            ty, rows, zc, xcd, wp = c.split(":")
-            cfgs.append(("xsplit", int(ty), int(rows), int(zc), int(xcd), int(wp)))
+            ty, rows, zc, xcd, wp, sh = c.split(":")
+            cfgs.append(("xsplit", int(ty), int(rows), int(zc), int(xcd), int(wp), int(sh)))
     else:
-        for wp in (0, 6, 8, 12, 16, 24, 32, 48, 64):
-            for ty, rows, zc in ((4, 2, 4), (8, 1, 8), (4, 1, 4)):
-                cfgs.append(("xsplit", ty, rows, zc, 1, wp))
+        for sh in (1, 0):
+            for ty, rows in ((4, 2), (4, 4), (2, 4), (4, 1), (8, 1), (8, 2), (2, 8), (4, 8)):
+                for zc in (4, 8, 16):
+                    cfgs.append(("xsplit", ty, rows, zc, 1, 0, sh))
     mgs = {lay: P.MultiGrid3D(ctx, [n] * 3, [0, 1, 0, 1, 0, 1], dtype, nlevels=1, layout=lay) for lay in ("natural", "xsplit")}
     e0, e1 = ctx.event(), ctx.event()
     times = {c: [] for c in cfgs}
     for r in range(args.rounds + 1):
         for c in cfgs:
-            lay, ty, rows, zc, xcd, wp = c
+            lay, ty, rows, zc, xcd, wp, sh = c
+            ctx.set_param("relax3d.shfl", sh)
             ctx.set_param("relax3d.ty", ty)
             ctx.set_param("relax3d.rows", rows)
             ctx.set_param("relax3d.wave_planes", wp)
@@ -65,7 +67,7 @@ def main():
         t = np.array(times[c])
         med, mn = float(np.median(t)), float(t.min())
         gbs = 3 * w * lups / (med * 1e-3) / 1e9
-        out.append(dict(layout=c[0], ty=c[1], rows=c[2], zchunk=c[3], xcd=c[4], wave_planes=c[5], ms_median=round(med, 4), ms_min=round(mn, 4),
+        out.append(dict(layout=c[0], ty=c[1], rows=c[2], zchunk=c[3], xcd=c[4], wave_planes=c[5], shfl=c[6], ms_median=round(med, 4), ms_min=round(mn, 4),
                          mlups=round(lups / (med * 1e-3) / 1e6, 1), alg_GBps=round(gbs, 1), frac_hbm=round(gbs / 8000.0, 4)))
     out.sort(key=lambda r: r["ms_median"])
     for r in out:
