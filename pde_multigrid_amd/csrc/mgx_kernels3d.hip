@@ -497,6 +497,118 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
     }
 }
 
+// ------------------------------------------------------------------ residual + restrict, streaming (XSplit)
+// Lane i of a wave owns the fine x-pair {2i, 2i+1} (= coarse column i) of the 2*CR+3 fine rows around CR
+// consecutive coarse rows and marches through a chunk of coarse planes.  v is carried in registers along z
+// (every v plane is loaded once), the y-neighbours are the thread's own rows, the x-neighbours come from the
+// adjacent lanes by wave shuffle; no LDS, no barrier.  The full-weighting formula of the reference groups its 27
+// terms by fine row (N3/MultiGrid3D.cpp:180: suffix _C / _N / _S = y, y-1, y+1), so each row contributes the
+// three sub-sums  a = C,  b = ((N+E)+S)+O,  c = ((NE+SE)+SO)+NO  over its 3 x 3 (x, z) neighbourhood and
+//   coarse = 1/8 a_C + 1/16 (b_C + (a_N + a_S)) + 1/32 ((c_C + b_N) + b_S) + 1/64 (c_N + c_S)
+// is exactly the reference's expression, association included.  Lane 0 of every wave is a halo lane (it only
+// supplies the x-1 residuals of lane 1), so a wave produces 63 coarse columns.  Boundary coarse points are not
+// written: the host zeroes the output planes first (restricted residual = 0 there, :704-705 then :113-119).
+template <class real, int MODE, int CR, int TYW>
+__global__ void __launch_bounds__(64 * TYW)
+    residual_restrict3d_xs_kernel(const real* __restrict__ v, const real* __restrict__ f, int sx, int sy, int szg, real hx2,
+                                  real hy2, real hz2, real* __restrict__ coarse, int cx, int cy, int czg, int pzchunk,
+                                  int fzoff, int czoff, int pzbeg, int pzend) {
+    constexpr int NR = 2 * CR + 3;  // fine rows held per lane: residual rows 1 .. NR-2 plus one v-only row each side
+    const Geo<XSplit, real> gf(sx, sy), gc(cx, cy);
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * 63 + lane;
+    const int cyb = 1 + (blockIdx.y * TYW + __builtin_amdgcn_readfirstlane(threadIdx.y)) * CR;
+    if (cyb > cy - 2 || i > cx - 1) return;
+    int pz0 = pzbeg + blockIdx.z * pzchunk;
+    const int pz1 = min(min(pz0 + pzchunk, pzend), czg - 1);
+    if (pz0 < 1) pz0 = 1;
+    if (pz0 >= pz1) return;
+    const bool hasB = i <= cx - 2;            // the odd-x entry 2i+1 exists
+    const bool xinA = i >= 1 && i <= cx - 2;  // x = 2i is interior
+    const bool lastlane = lane == 63;
+    const int yf0 = 2 * cyb - 2;
+    size_t roff[NR];
+    bool yin[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int y = yf0 + r;
+        roff[r] = (size_t)min(y, sy - 1) * gf.P;
+        yin[r] = y >= 1 && y <= sy - 2;
+    }
+    const size_t PL = gf.PL;
+    auto loadA = [&](int g, real (&A)[NR]) {  // even-x entries of global fine plane g
+        const size_t pb = (size_t)(g - fzoff) * PL + i;
+#pragma unroll
+        for (int r = 0; r < NR; r++) A[r] = v[pb + roff[r]];
+    };
+    auto loadB = [&](int g, real (&B)[NR]) {  // odd-x entries
+        const size_t pb = (size_t)(g - fzoff) * PL + gf.H + (hasB ? i : 0);
+#pragma unroll
+        for (int r = 0; r < NR; r++) B[r] = v[pb + roff[r]];
+    };
+    // residuals of fine plane g on rows 1 .. NR-2 for x = 2i (rA) and x = 2i+1 (rB); 0 outside the interior
+    auto resid = [&](int g, const real (&AP)[NR], const real (&BP)[NR], const real (&AC)[NR], const real (&BC)[NR],
+                     const real (&AN)[NR], const real (&BN)[NR], real (&rA)[NR - 2], real (&rB)[NR - 2]) {
+        const bool zin = g >= 1 && g <= szg - 2;
+        const size_t pb = (size_t)(g - fzoff) * PL;
+#pragma unroll
+        for (int r = 1; r < NR - 1; r++) {
+            const real fA = f[pb + roff[r] + i];
+            const real fB = f[pb + roff[r] + gf.H + (hasB ? i : 0)];
+            const real Bl = __shfl_up(BC[r], 1, 64);                                     // v(2i-1): odd entry of lane i-1
+            real Ar = __shfl_down(AC[r], 1, 64);                                         // v(2i+2): even entry of lane i+1
+            if (lastlane && hasB) Ar = v[pb + roff[r] + i + 1];                          // wave edge: load it
+            const real a = residual3d_point<real, MODE>(Bl, BC[r], AC[r - 1], AC[r + 1], AP[r], AN[r], AC[r], fA, hx2, hy2, hz2);
+            const real b = residual3d_point<real, MODE>(AC[r], Ar, BC[r - 1], BC[r + 1], BP[r], BN[r], BC[r], fB, hx2, hy2, hz2);
+            rA[r - 1] = (zin && yin[r] && xinA && lane > 0) ? a : (real)0;
+            rB[r - 1] = (zin && yin[r] && hasB) ? b : (real)0;
+        }
+    };
+    real AP[NR], BP[NR], AC[NR], BC[NR], AN[NR], BN[NR];
+    real rAm[NR - 2], rBm[NR - 2], rA0[NR - 2], rB0[NR - 2], rAp[NR - 2], rBp[NR - 2];
+    // prologue: v planes 2pz0-2, 2pz0-1, 2pz0 and the residual of plane 2pz0-1
+    loadA(2 * pz0 - 2, AP); loadB(2 * pz0 - 2, BP);
+    loadA(2 * pz0 - 1, AC); loadB(2 * pz0 - 1, BC);
+    loadA(2 * pz0, AN);     loadB(2 * pz0, BN);
+    resid(2 * pz0 - 1, AP, BP, AC, BC, AN, BN, rAm, rBm);
+    for (int pz = pz0; pz < pz1; pz++) {
+        // plane 2pz: shift the v window, load plane 2pz+1
+#pragma unroll
+        for (int r = 0; r < NR; r++) { AP[r] = AC[r]; BP[r] = BC[r]; AC[r] = AN[r]; BC[r] = BN[r]; }
+        loadA(2 * pz + 1, AN); loadB(2 * pz + 1, BN);
+        resid(2 * pz, AP, BP, AC, BC, AN, BN, rA0, rB0);
+        // plane 2pz+1: shift, load plane 2pz+2
+#pragma unroll
+        for (int r = 0; r < NR; r++) { AP[r] = AC[r]; BP[r] = BC[r]; AC[r] = AN[r]; BC[r] = BN[r]; }
+        loadA(2 * pz + 2, AN); loadB(2 * pz + 2, BN);
+        resid(2 * pz + 1, AP, BP, AC, BC, AN, BN, rAp, rBp);
+        // per-row sub-sums a, b, c of residual rows 0 .. 2CR (x-1 values: rB of lane i-1)
+        real sa[NR - 2], sb[NR - 2], sc[NR - 2];
+#pragma unroll
+        for (int r = 0; r < NR - 2; r++) {
+            const real lm = __shfl_up(rBm[r], 1, 64), l0 = __shfl_up(rB0[r], 1, 64), lp = __shfl_up(rBp[r], 1, 64);
+            sa[r] = rA0[r];
+            sb[r] = ((rAp[r] + rB0[r]) + rAm[r]) + l0;      // (N + E + S + O): (x,z+1), (x+1,z), (x,z-1), (x-1,z)
+            sc[r] = ((rBp[r] + rBm[r]) + lm) + lp;          // (NE + SE + SO + NO)
+        }
+        if (xinA && lane > 0) {
+#pragma unroll
+            for (int c = 0; c < CR; c++) {
+                const int py = cyb + c;
+                if (py <= cy - 2) {
+                    const int rn = 2 * c, rc = 2 * c + 1, rs = 2 * c + 2;  // residual rows y-1, y, y+1 of this coarse row
+                    coarse[gc.row(py, pz - czoff) + gc.pos(i)] =
+                        (1 / 8.0f) * (sa[rc]) + (1 / 16.0f) * (sb[rc] + (sa[rn] + sa[rs])) +
+                        (1 / 32.0f) * ((sc[rc] + sb[rn]) + sb[rs]) + (1 / 64.0f) * (sc[rn] + sc[rs]);
+                }
+            }
+        }
+        // plane 2pz+1 becomes the next step's plane 2(pz+1)-1
+#pragma unroll
+        for (int r = 0; r < NR - 2; r++) { rAm[r] = rAp[r]; rBm[r] = rBp[r]; }
+    }
+}
+
 // ------------------------------------------------------------------ sum of squares
 template <class real>
 __global__ void __launch_bounds__(256) sumsq_kernel(const real* __restrict__ x, size_t count, double* __restrict__ out) {
@@ -716,6 +828,30 @@ int set3d(mgx_ctx* ctx, real* g, const int n[3], real value, int modify_boundari
     return MGX_OK;
 }
 
+// streaming x-split residual+restrict over the global coarse planes [pzbeg, pzend): zero them (boundary coarse
+// points stay 0), then one launch of residual_restrict3d_xs_kernel
+template <class real>
+static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real* f, const int n[3], real hx2, real hy2,
+                                         real hz2, int mode, real* coarse_f, const int cn[3], int fzoff, int czoff, int pzbeg,
+                                         int pzend) {
+    constexpr int CR = 2, TYW = 4;
+    const Geo<XSplit, real> gc(cn[0], cn[1]);
+    MGX_HIP(hipMemsetAsync(coarse_f + gc.PL * (size_t)(pzbeg - czoff), 0, gc.PL * (size_t)(pzend - pzbeg) * sizeof(real),
+                           ctx->compute));
+    if (cn[0] < 3 || cn[1] < 3) return MGX_OK;
+    const int gx = ceil_div(cn[0], 63), gy = ceil_div(cn[1] - 2, CR * TYW);
+    int pzchunk = ctx->rr_pzchunk > 0 ? ctx->rr_pzchunk : 8;
+    while (pzchunk > 1 && (long long)gx * gy * ceil_div(pzend - pzbeg, pzchunk) < 4LL * ctx->num_cus) pzchunk >>= 1;
+    dim3 g(gx, gy, ceil_div(pzend - pzbeg, pzchunk));
+    if (mode == MGX_RESIDUAL_REF_COMPAT)
+        hipLaunchKernelGGL((residual_restrict3d_xs_kernel<real, 0, CR, TYW>), g, dim3(64, TYW, 1), 0, ctx->compute, v, f, n[0],
+                           n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend);
+    else
+        hipLaunchKernelGGL((residual_restrict3d_xs_kernel<real, 1, CR, TYW>), g, dim3(64, TYW, 1), 0, ctx->compute, v, f, n[0],
+                           n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend);
+    return MGX_OK;
+}
+
 template <class real, class L>
 int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[3], const real h[3], int mode,
                         real* coarse_f, const int cn[3]) {
@@ -727,6 +863,12 @@ int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[
     MGX_REQUIRE(mode == MGX_RESIDUAL_REF_COMPAT || mode == MGX_RESIDUAL_CORRECT, MGX_ERR_INVALID,
                 "residual_restrict3d: bad mode %d", mode);
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    if (L::xsplit && ctx->rr_stream) {
+        st = residual_restrict3d_xs_launch<real>(ctx, v, f, n, hx2, hy2, hz2, mode, coarse_f, cn, 0, 0, 0, cn[2]);
+        if (st) return st;
+        MGX_LAUNCH_CHECK();
+        return MGX_OK;
+    }
     constexpr int CTX = 32, CTY = 8;
     const int tiles = ceil_div(cn[0], CTX) * ceil_div(cn[1], CTY);
     int pzchunk = ctx->rr_pzchunk > 0 ? ctx->rr_pzchunk : 8;  // coarse planes per block (1 extra fine plane per chunk)
@@ -802,6 +944,12 @@ int residual_restrict3d_slab(mgx_ctx* ctx, const real* v, const real* f, const i
                 "residual_restrict_slab: bad plane range");
     if (pzbeg == pzend) return MGX_OK;
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    if (ctx->rr_stream) {
+        st = residual_restrict3d_xs_launch<real>(ctx, v, f, n, hx2, hy2, hz2, mode, coarse_f, cn, fzoff, czoff, pzbeg, pzend);
+        if (st) return st;
+        MGX_LAUNCH_CHECK();
+        return MGX_OK;
+    }
     constexpr int CTX = 32, CTY = 8;
     const int tiles = ceil_div(cn[0], CTX) * ceil_div(cn[1], CTY);
     int pzchunk = ctx->rr_pzchunk > 0 ? ctx->rr_pzchunk : 8;
@@ -996,6 +1144,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "relax3d.xcd")) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "relax3d.xcd must be 0, 1 or 2");
         ctx->relax_xcd = value;
+    } else if (!strcmp(name, "residual_restrict3d.stream")) {
+        ctx->rr_stream = value ? 1 : 0;  // 1 = streaming shuffle kernel (x-split), 0 = LDS rolling-window kernel
     } else if (!strcmp(name, "residual_restrict3d.pzchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "residual_restrict3d.pzchunk must be >= 0 (0 = automatic)");
         ctx->rr_pzchunk = value;

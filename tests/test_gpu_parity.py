@@ -98,6 +98,27 @@ def test_3d_smallest_grid_and_zero_sweeps(ctx, layout):
     assert_f64(ops.residual(ctx, v, f, n3, rg), O.residual3d(n3, rg, v, f, dtype=np.float64))
 
 
+@pytest.mark.parametrize("n3", [(9, 9, 9), (33, 17, 65), (129, 65, 17), (257, 33, 9)])
+@pytest.mark.parametrize("stream", [0, 1])
+def test_3d_xsplit_residual_restrict_variants(ctx, n3, stream):
+    """both x-split residual+restrict kernels (LDS rolling window / streaming shuffles) == oracle, all chunkings"""
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(sum(n3) + stream)
+    ctx.set_param("residual_restrict3d.stream", stream)
+    try:
+        for dtype in (np.float32, np.float64):
+            v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+            f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+            for mode in (P.REF_COMPAT, P.CORRECT):
+                want = O.restrict3d(n3, O.residual3d(n3, rg, v, f, mode, dtype=dtype), dtype=dtype)
+                for chunk in (0, 1, 3):
+                    ctx.set_param("residual_restrict3d.pzchunk", chunk)
+                    assert bits_equal(P.ops3dxs.residual_restrict(ctx, v, f, n3, rg, mode), want)
+    finally:
+        ctx.set_param("residual_restrict3d.stream", 1)
+        ctx.set_param("residual_restrict3d.pzchunk", 0)
+
+
 def test_3d_xsplit_pack_unpack(ctx):
     """device Natural <-> XSplit conversion against the numpy restatement of the layout"""
     rng = np.random.default_rng(11)
@@ -133,7 +154,7 @@ def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, rows, zchun
                 assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, k), O.relax3d(n3, rg, v, f, k, dtype=np.float64))
     finally:
         ctx.set_param("relax3d.ty", 4)
-        ctx.set_param("relax3d.rows", 2)
+        ctx.set_param("relax3d.rows", 4)
         ctx.set_param("relax3d.zchunk", 0)
         ctx.set_param("relax3d.xcd", 1)
         ctx.set_param("relax3d.wave_planes", -1)
