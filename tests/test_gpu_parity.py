@@ -157,7 +157,7 @@ def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, rows, zchun
         ctx.set_param("relax3d.rows", 4)
         ctx.set_param("relax3d.zchunk", 0)
         ctx.set_param("relax3d.xcd", 1)
-        ctx.set_param("relax3d.wave_planes", -1)
+        ctx.set_param("relax3d.wave_planes", 0)
 
 
 def test_3d_size_violations_return_status(ctx):
