@@ -62,8 +62,11 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
 
+    # MGX_BENCH_FORCE_DIST=1 runs the slab-decomposed code path (torch rendezvous, RCCL communicator, slab
+    # hierarchy) even with one rank: a plumbing check for boxes with a single GPU
+    force_dist = os.environ.get("MGX_BENCH_FORCE_DIST", "0") == "1"
     dist = None
-    if world > 1:
+    if world > 1 or force_dist:
         # torch BEFORE libmgx (pde_multigrid_amd/_lib.py: load order of the ROCm runtime libraries)
         import torch
         import torch.distributed as dist  # control plane only (rendezvous, barrier, max over ranks); data plane = RCCL in libmgx
@@ -78,7 +81,7 @@ def main():
     n = args.n or (513 if world == 1 else 1025)
     ctx = P.Context(local_rank)
 
-    if world == 1:
+    if world == 1 and not force_dist:
         mg = P.MultiGrid3D(ctx, [n] * 3, R3, dtype)
         reset = lambda: mg.setToValue_v(0, 0.0, True)  # noqa: E731
         nd = 0
@@ -119,7 +122,7 @@ def main():
     # ---- smoother-only region for the roofline (HIP events on the compute stream) -------
     reset()
     e0, e1 = ctx.event(), ctx.event()
-    if world == 1:
+    if world == 1 and not force_dist:
         # the smoother exactly as the cycle calls it: Relax(grid, v1) = v1 red-black sweeps per call
         mg.Relax(0, args.v1)
         ctx.sync()
