@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=0, help="points per axis of the finest grid (2^k+1); 0 = 513 (N=1) / 1025 (N>1)")
+    ap.add_argument("--size", dest="n", type=int, default=0, help="points per axis of the finest grid (2^k+1); 0 = 513 (N=1) / 1025 (N>1)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--v1", type=int, default=2)
     ap.add_argument("--v2", type=int, default=2)
