@@ -70,11 +70,13 @@ __global__ void __launch_bounds__(256) relax3d_colour_kernel(real* __restrict__ 
 // hit in L1/L2, R stores.  All R rows' loads are issued before the first use, which keeps
 // R x 16 bytes of HBM traffic in flight per lane.  vin and vout alias the same array; the entries
 // read and the entries written are disjoint by colour, which is what makes __restrict__ legitimate.
-// ABL != 0 builds diagnostic variants for tools/sweep_relax.py ("relax3d.ablate"; results are WRONG):
-// 1 = no f load, 2 = no store (one lane keeps the value alive), 4 = no side / edge-row loads, 8 = no division.
-// SHFL: the side value of a lane is the "own" value of the neighbouring lane, so it is taken with a wave
-// shuffle instead of a second (L1/L2-hit) load; only the wave's edge lane still loads it.
-template <class real, int TYW, int R, int ABL = 0, bool SHFL = true>
+// The results are written with non-temporal stores: they are next read by the following colour pass, long after
+// they would have been evicted, and keeping them out of L2 leaves it to the re-used other-colour rows/planes
+// (measured +9 %; non-temporal loads of f or v do not pay).
+// ABL != 0 builds diagnostic variants for tools/ablate_relax.py ("relax3d.ablate"; results are WRONG except 16):
+// 1 = no f load, 2 = no store (one lane keeps the value alive), 4 = no side / edge-row loads, 8 = no division,
+// 16 = plain instead of non-temporal stores (correct results; A/B switch).
+template <class real, int TYW, int R, int ABL = 0>
 __global__ void __launch_bounds__(64 * TYW)
     relax3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                       int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
@@ -146,14 +148,13 @@ __global__ void __launch_bounds__(64 * TYW)
             U[r] = vin[rowb[r] + sxy + hq + j];
             if (ABL & 4) {
                 side[r] = c_cur[r];
-            } else if (SHFL) {
+            } else {
+                // the side value is the "own" value of the neighbouring lane: wave shuffle instead of a second load;
                 // neighbour lane: j+1 when q_r = 1, j-1 when q_r = 0 (q_r is wave-uniform).  The wave's edge lane,
                 // and the last active lane (its neighbour j+1 = M-1 holds the boundary entry but has exited), load.
                 const real nb = qr ? __shfl_down(c_cur[r], 1, 64) : __shfl_up(c_cur[r], 1, 64);
                 const bool edge = qr ? (threadIdx.x == 63 || j == M - 2) : (threadIdx.x == 0);
                 side[r] = edge ? vin[rowb[r] + ho + j + (qr ? 1 : -1) + (qr | j ? 0 : M)] : nb;
-            } else {
-                side[r] = vin[rowb[r] + ho + j + (qr ? 1 : -1) + (qr | j ? 0 : M)];
             }
             fv[r] = (ABL & 1) ? (real)1 : f[rowb[r] + hq + j];
         }
@@ -170,7 +171,10 @@ __global__ void __launch_bounds__(64 * TYW)
             if (ABL & 8) out = (W + E + N + S + c_prev[r] + U[r] - fv[r]) * hx2;
             if (ABL & 2) {
                 if (out == (real)123456.789) vout[rowb[r] + qr * H + j] = out;
-            } else if ((qr | j) && r < nrows) vout[rowb[r] + qr * H + j] = out;  // x = 2j+q_r >= 1
+            } else if ((qr | j) && r < nrows) {  // x = 2j+q_r >= 1
+                if (ABL & 16) vout[rowb[r] + qr * H + j] = out;
+                else __builtin_nontemporal_store(out, &vout[rowb[r] + qr * H + j]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -662,24 +666,20 @@ static void launch_xs(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int 
     const int M = (sx + 1) / 2;
     const int gx = ceil_div(M - 1, 64), gy = ceil_div(sy - 2, TYW * R), gz = ceil_div(zend - zbeg, zchunk);
     const unsigned nblocks = ctx->relax_xcd == 2 ? 8u * ((gx * gy + 7) / 8) * gz : (unsigned)gx * gy * gz;
-    if (TYW == 4 && R == 2 && ctx->relax_ablate) {  // diagnostics only
+    if (TYW == 4 && R == 4 && ctx->relax_ablate) {  // diagnostics only
 #define MGX_ABL(A)                                                                                                   \
     case A:                                                                                                          \
-        hipLaunchKernelGGL((relax3d_xs_kernel<real, 4, 2, A, false>), dim3(nblocks), dim3(64, 4, 1), 0, ctx->compute,       \
+        hipLaunchKernelGGL((relax3d_xs_kernel<real, 4, 4, A>), dim3(nblocks), dim3(64, 4, 1), 0, ctx->compute,          \
                            (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd); \
         return;
         switch (ctx->relax_ablate) {
-            MGX_ABL(1) MGX_ABL(2) MGX_ABL(3) MGX_ABL(4) MGX_ABL(5) MGX_ABL(7) MGX_ABL(8) MGX_ABL(12) MGX_ABL(15)
+            MGX_ABL(1) MGX_ABL(2) MGX_ABL(3) MGX_ABL(4) MGX_ABL(5) MGX_ABL(7) MGX_ABL(8) MGX_ABL(12) MGX_ABL(15) MGX_ABL(16)
             default: break;
         }
 #undef MGX_ABL
     }
-    if (ctx->relax_shfl)
-        hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R, 0, true>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
-                           (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
-    else
-        hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R, 0, false>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
-                           (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
+    hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
+                       (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
 }
 
 template <class real, int TYW>
@@ -1132,8 +1132,6 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "relax3d.ty")) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.ty (waves per block) must be 1, 2, 4 or 8");
         ctx->relax_ty = value;
-    } else if (!strcmp(name, "relax3d.shfl")) {
-        ctx->relax_shfl = value ? 1 : 0;
     } else if (!strcmp(name, "relax3d.ablate")) {
         ctx->relax_ablate = value;  // diagnostics: non-zero gives WRONG results (see relax3d_xs_kernel)
     } else if (!strcmp(name, "relax3d.wave_planes")) {

@@ -144,9 +144,6 @@ def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, rows, zchun
         for xcd in (0, 1, 2):
             ctx.set_param("relax3d.xcd", xcd)
             assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 3), O.relax3d(n3, rg, v, f, 3, dtype=np.float64))
-        ctx.set_param("relax3d.shfl", 0)
-        assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 2), O.relax3d(n3, rg, v, f, 2, dtype=np.float64))
-        ctx.set_param("relax3d.shfl", 1)
         # time-skewed pass order over z-slabs of every height, including degenerate ones
         for wp in (1, 2, 3, 5, 8, 13, 39, 64):
             ctx.set_param("relax3d.wave_planes", wp)

@@ -46,7 +46,6 @@ def main():
     for r in range(args.rounds + 1):
         for c in cfgs:
             lay, ty, rows, zc, xcd, wp, sh = c
-            ctx.set_param("relax3d.shfl", sh)
             ctx.set_param("relax3d.ty", ty)
             ctx.set_param("relax3d.rows", rows)
             ctx.set_param("relax3d.wave_planes", wp)
