@@ -19,6 +19,7 @@ struct mgx_ctx {
     int relax_xcd = 1;     // XCD-aware block -> tile mapping
     int relax_rows = 4;    // consecutive rows per lane (register blocking in y) of relax3d_xs_kernel
     int relax_wave_planes = 0;  // time-skewed slab height of relax3d_xsplit: 0 off (measured slower: the L2-miss path, not HBM, is the limit), <0 automatic
+    int relax_small = 1;   // levels <= 17^3: all sweeps of a Relax call in one workgroup (LDS resident)
     int relax_ablate = 0;  // diagnostic kernel variants (tools only)
     int rr_stream = 1;     // x-split residual+restrict: streaming shuffle kernel (1) or LDS window kernel (0)
     int rr_pzchunk = 0;    // coarse planes per block of residual_restrict3d_kernel, 0 = automatic

@@ -186,6 +186,53 @@ __global__ void __launch_bounds__(64 * TYW)
     }
 }
 
+// ------------------------------------------------------------------ relax, whole small level in one workgroup
+// Levels up to 17^3 (<= 4913 points) are pure launch latency with one launch per colour pass (about 5 us each;
+// the thesis runs 3000 sweeps per level).  Here ONE workgroup keeps v and f of the whole level in LDS (2 x 38 KB
+// in fp64) and runs all `ncycles` red-black sweeps with a barrier between colour passes.  Same per-point
+// expression, same colour order: bit-identical to the multi-launch path.
+constexpr int SMALL_MAX = 17;
+template <class real, class L>
+__global__ void __launch_bounds__(1024) relax3d_small_kernel(real* __restrict__ v, const real* __restrict__ f, int sx, int sy,
+                                                             int sz, real hx2, real hy2, real hz2, int ncycles) {
+    __shared__ real sv[SMALL_MAX * SMALL_MAX * SMALL_MAX];
+    __shared__ real sf[SMALL_MAX * SMALL_MAX * SMALL_MAX];
+    constexpr int PT = (SMALL_MAX * SMALL_MAX * SMALL_MAX + 1023) / 1024;  // points per thread
+    const Geo<L, real> g(sx, sy);
+    const int n = sx * sy * sz, sxy = sx * sy;
+    size_t gidx[PT];
+    int kind[PT];  // -1 = not a point / boundary, else the colour of the interior point
+#pragma unroll
+    for (int k = 0; k < PT; k++) {
+        const int t = threadIdx.x + k * 1024;
+        kind[k] = -1;
+        gidx[k] = 0;
+        if (t < n) {
+            const int z = t / sxy, y = (t - z * sxy) / sx, x = t - z * sxy - y * sx;
+            gidx[k] = g.row(y, z) + g.pos(x);
+            sv[t] = v[gidx[k]];
+            sf[t] = f[gidx[k]];
+            if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1 && z > 0 && z < sz - 1) kind[k] = (x + y + z) & 1;
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < 2 * ncycles; c++) {
+        const int colour = c & 1;  // red = 0 first (N3/MultiGrid3D.cpp:515), then black (:544)
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            if (kind[k] == colour) {
+                const int t = threadIdx.x + k * 1024;
+                sv[t] = relax3d_point<real>(sv[t - 1], sv[t + 1], sv[t - sx], sv[t + sx], sv[t - sxy], sv[t + sxy], sf[t], hx2,
+                                            hy2, hz2);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < PT; k++)
+        if (kind[k] >= 0) v[gidx[k]] = sv[threadIdx.x + k * 1024];
+}
+
 // ------------------------------------------------------------------ weighted Jacobi (addition)
 // north_star names weighted Jacobi next to red-black Gauss-Seidel; the reference only has the latter (Jacobi is
 // pseudo-code in the thesis).  One sweep: vout = v + omega * (u - v), u = the Gauss-Seidel value of
@@ -749,6 +796,12 @@ int relax3d(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3
     if (st) return st;
     MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "relax3d: ncycles = %d < 0", ncycles);
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // N3/MultiGrid3D.cpp:498-500
+    if (ncycles > 0 && n[0] <= SMALL_MAX && n[1] <= SMALL_MAX && n[2] <= SMALL_MAX && ctx->relax_small) {
+        hipLaunchKernelGGL((relax3d_small_kernel<real, L>), dim3(1), dim3(1024), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2,
+                           hz2, ncycles);
+        MGX_LAUNCH_CHECK();
+        return MGX_OK;
+    }
     if (L::xsplit) st = relax3d_xsplit<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles);
     else st = relax3d_natural<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles);
     if (st) return st;
@@ -1132,6 +1185,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "relax3d.ty")) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.ty (waves per block) must be 1, 2, 4 or 8");
         ctx->relax_ty = value;
+    } else if (!strcmp(name, "relax3d.small")) {
+        ctx->relax_small = value ? 1 : 0;  // one-workgroup LDS kernel for levels <= 17^3
     } else if (!strcmp(name, "relax3d.ablate")) {
         ctx->relax_ablate = value;  // diagnostics: non-zero gives WRONG results (see relax3d_xs_kernel)
     } else if (!strcmp(name, "relax3d.wave_planes")) {

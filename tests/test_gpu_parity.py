@@ -119,6 +119,24 @@ def test_3d_xsplit_residual_restrict_variants(ctx, n3, stream):
         ctx.set_param("residual_restrict3d.pzchunk", 0)
 
 
+@pytest.mark.parametrize("layout", ["natural", "xsplit"])
+@pytest.mark.parametrize("n3", [(3, 3, 3), (5, 9, 17), (17, 17, 17), (17, 5, 3), (9, 17, 9)])
+def test_3d_small_level_one_workgroup_relax(ctx, n3, layout):
+    """levels <= 17^3: all sweeps of a Relax call in one workgroup with v, f in LDS == multi-launch path == oracle"""
+    ops = OPS3[layout]
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(sum(n3))
+    for dtype in (np.float32, np.float64):
+        v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+        f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+        for k in (1, 2, 7):
+            want = O.relax3d(n3, rg, v, f, k, dtype=dtype)
+            for small in (1, 0):
+                ctx.set_param("relax3d.small", small)
+                assert bits_equal(ops.relax(ctx, v, f, n3, rg, k), want)
+    ctx.set_param("relax3d.small", 1)
+
+
 def test_3d_xsplit_pack_unpack(ctx):
     """device Natural <-> XSplit conversion against the numpy restatement of the layout"""
     rng = np.random.default_rng(11)
