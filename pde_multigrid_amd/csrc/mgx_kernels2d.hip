@@ -117,6 +117,55 @@ __global__ void __launch_bounds__(256) set2d_kernel(real* __restrict__ g, int sx
     g[x + (size_t)y * sx] = value;
 }
 
+// Levels up to 65^2 (<= 4225 points): all `ncycles` red-black sweeps of a Relax call in ONE workgroup with v and f
+// in LDS and a barrier between colour passes (see relax3d_small_kernel); bit-identical to the multi-launch path.
+constexpr int SMALL2_MAX = 65;
+template <class real>
+__global__ void __launch_bounds__(1024) relax2d_small_kernel(real* __restrict__ v, const real* __restrict__ f, int sx, int sy,
+                                                             Lyap2<real> k, int ncycles) {
+    __shared__ real sv[SMALL2_MAX * SMALL2_MAX];
+    __shared__ real sf[SMALL2_MAX * SMALL2_MAX];
+    constexpr int PT = (SMALL2_MAX * SMALL2_MAX + 1023) / 1024;
+    const int n = sx * sy;
+    int kind[PT];
+    real hyK1[PT], hxK2[PT], den[PT];  // per-point coefficients (:230-236), constant over the sweeps
+#pragma unroll
+    for (int p = 0; p < PT; p++) {
+        const int t = threadIdx.x + p * 1024;
+        kind[p] = -1;
+        hyK1[p] = hxK2[p] = den[p] = (real)0;
+        if (t < n) {
+            const int y = t / sx, x = t - y * sx;
+            sv[t] = v[t];
+            sf[t] = f[t];
+            if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1) {
+                kind[p] = (x + y) & 1;
+                const real xj = k.ax + x * k.hx;
+                const real yi = k.ay + y * k.hy;
+                const real K1 = k.A0 * xj + k.A1 * yi;
+                const real K2 = k.A2 * xj + k.A3 * yi;
+                den[p] = K1 * k.hy + K2 * k.hx - k.alfa * k.hx * k.hy;
+                hyK1[p] = k.hy * K1;
+                hxK2[p] = k.hx * K2;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < 2 * ncycles; c++) {
+        const int colour = c & 1;
+#pragma unroll
+        for (int p = 0; p < PT; p++)
+            if (kind[p] == colour) {
+                const int t = threadIdx.x + p * 1024;
+                sv[t] = (hyK1[p] * sv[t + 1] + hxK2[p] * sv[t + sx] - sf[t] * k.hx * k.hy) / (den[p]);  // :241
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < PT; p++)
+        if (kind[p] >= 0) v[threadIdx.x + p * 1024] = sv[threadIdx.x + p * 1024];
+}
+
 // weighted Jacobi (addition, see mgx_kernels3d.hip): vout = v + omega*(u - v), u = the Gauss-Seidel value (:241)
 template <class real>
 __global__ void __launch_bounds__(256) jacobi2d_kernel(const real* __restrict__ v, real* __restrict__ vout,
@@ -201,6 +250,11 @@ int relax2d(mgx_ctx* ctx, real* v, const real* f, const int n[2], const real h[2
     if (st) return st;
     MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "relax2d: ncycles = %d < 0", ncycles);
     const Lyap2<real> k = lyap<real>(h, a, A, alfa);
+    if (ncycles > 0 && n[0] <= SMALL2_MAX && n[1] <= SMALL2_MAX) {
+        hipLaunchKernelGGL((relax2d_small_kernel<real>), dim3(1), dim3(1024), 0, ctx->compute, v, f, n[0], n[1], k, ncycles);
+        MGX_LAUNCH_CHECK();
+        return MGX_OK;
+    }
     dim3 g(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), 1);
     for (int c = 0; c < ncycles; c++)
         for (int colour = 0; colour < 2; colour++)
