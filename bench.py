@@ -50,7 +50,9 @@ def main():
     ap.add_argument("--v1", type=int, default=2)
     ap.add_argument("--v2", type=int, default=2)
     ap.add_argument("--smoother-sweeps", type=int, default=20, help="sweeps in the smoother-only roofline region")
-    ap.add_argument("--min-planes", type=int, default=4, help="N>1: a level stays distributed while every GPU owns this many planes")
+    ap.add_argument("--min-planes", type=int, default=32,
+                    help="N>1: a level stays distributed while every GPU owns this many planes; coarser levels are replicated "
+                         "(below about 32 planes per GPU the ghost exchanges are pure latency)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -52,16 +52,26 @@ def _rank_main(rank, world, port, n, v1, v2, cycles, min_planes, mode, out_path)
         for r in reqs:
             r.wait()
 
-    def exchange_v(l):  # 2 planes up, 1 plane down (slab_exchange_)
+    def exchange_v(l):  # 1 plane up, 1 plane down (slab_exchange_): ghosts zlo-1 and zhi
         p, a = plans[l], v[l]
         top = p.zhi - 1 if rank == world - 1 else p.zhi
-        lo_buf = np.empty((2,) + a.shape[1:], dtype) if rank > 0 else None
+        lo_buf = np.empty((1,) + a.shape[1:], dtype) if rank > 0 else None
         up_buf = np.empty((1,) + a.shape[1:], dtype) if rank < world - 1 else None
-        sendrecv(a[p.zlo:p.zlo + 1], lo_buf, a[top - 2:top], up_buf)
         if rank > 0:
-            a[p.zlo - 2:p.zlo] = lo_buf
+            a[p.zlo - 2] = np.nan  # the second ghost goes stale: only exchange_v2 may make it valid again
+        sendrecv(a[p.zlo:p.zlo + 1], lo_buf, a[top - 1:top], up_buf)
+        if rank > 0:
+            a[p.zlo - 1:p.zlo] = lo_buf
         if rank < world - 1:
             a[p.zhi:p.zhi + 1] = up_buf
+
+    def exchange_v2(l):  # slab_exchange2_: ghost zlo-2 <- lower neighbour's plane top-2
+        p, a = plans[l], v[l]
+        top = p.zhi - 1 if rank == world - 1 else p.zhi
+        lo_buf = np.empty((1,) + a.shape[1:], dtype) if rank > 0 else None
+        sendrecv(None, lo_buf, a[top - 2:top - 1], None)
+        if rank > 0:
+            a[p.zlo - 2:p.zlo - 1] = lo_buf
 
     def exchange_f_up(l):  # slab_exchange_f_
         p, a = plans[l], f[l]
@@ -88,6 +98,7 @@ def _rank_main(rank, world, port, n, v1, v2, cycles, min_planes, mode, out_path)
         N = sizes[l] - 1
         relax(l, v1)
         if l != numGrids - 1:
+            exchange_v2(l)
             poison(v[l], p)
             poison(f[l], p)
             r = O.residual3d(s3, R3, v[l], f[l], mode, dtype)

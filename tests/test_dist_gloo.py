@@ -3,8 +3,9 @@
 
 Each rank keeps whole-grid arrays but may only READ the planes of its slab window
 [zoff, zoff+nzl) -- everything else is poisoned with NaN before every operator -- and only KEEPS
-the planes it owns.  Ownership, ghost depths (2 below, 1 above), the exchange schedule (after every
-colour pass, after the correction, f's lower ghost after restriction) and the agglomeration level
+the planes it owns.  Ownership, ghost depths (2 below, 1 above), the exchange schedule (adjacent ghosts after
+every colour pass and after the correction, the second lower ghost right before the residual, f's lower
+ghost after restriction) and the agglomeration level
 come from the product's own plan functions (mg_slab_plan / mg_dist_num_levels in libmgx, pure host
 code).  The assembled result must equal the single-domain oracle bit for bit; a wrong ghost depth or a
 missing exchange shows up as NaN or as a differing bit pattern.  The real C driver with the HIP kernels
