@@ -199,6 +199,14 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx3dxs_interpolate_correct_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff,        \
                                                const real* coarse_v, const int cn[3], int czoff,        \
                                                int pzbeg, int pzend);                                   \
+    /* _colour forms: only the points with (x + y + z_global) % 2 == colour are corrected (-1 = all).  */ \
+    /* The cycle passes colour 1 (black) when red-black sweeps follow: the red pass rewrites every red */ \
+    /* interior point from black neighbours alone, so a corrected red value is never read.            */ \
+    int mgx3dxs_interpolate_correct_colour_##SFX(mgx_ctx* ctx, real* v, const int n[3],                 \
+                                                 const real* coarse_v, const int cn[3], int colour);    \
+    int mgx3dxs_interpolate_correct_colour_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff, \
+                                                      const real* coarse_v, const int cn[3], int czoff, \
+                                                      int pzbeg, int pzend, int colour);                \
     int mgx2d_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[2], const real h[2],        \
                           const real a[2], const real A[4], int alfa, int ncycles);                     \
     int mgx2d_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[2],       \

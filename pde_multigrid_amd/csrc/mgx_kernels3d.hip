@@ -137,29 +137,74 @@ __global__ void __launch_bounds__(64 * TYW)
         c_prev[r] = vin[rowb[r] - sxy + qr * H + j];   // (half q_r,   j, plane z0-1)
         c_cur[r] = vin[rowb[r] + (1 - qr) * H + j];    // (half 1-q_r, j, plane z0)
     }
+    // EARLY (ABL & 32): the values that come from outside the thread's own column -- N of row 0, S of row R-1 and
+    // the side value of the wave's edge lanes -- are loaded one plane ahead, in the same step in which the
+    // neighbouring wave streams exactly those entries in as its U.  Both requests then reach L2 together (one
+    // fill) instead of a full step apart, by which time the XCD's waves have streamed more than the 4 MiB of L2
+    // through it and the line has been evicted (PMC: these re-loads were 27-50 % misses).
+    constexpr bool EARLY = (ABL & 32) != 0;
+    auto side_edge = [&](int r, int qr) -> bool {  // does this lane load its side value from memory?
+        return qr ? (threadIdx.x == 63 || j == M - 2) : (threadIdx.x == 0);
+    };
+    auto side_addr = [&](int r, int qr, size_t plane_off) -> size_t {
+        return rowb[r] + plane_off + (1 - qr) * H + j + (qr ? 1 : -1) + (qr | j ? 0 : M);
+    };
+    real Nnext = 0, Snext = 0, side_next[R];
+    size_t rowS = g.row(min(y0 + R, sy - 1), z0);  // the row below the thread's rows (clamped: never past the plane)
+    if (EARLY) {
+        Nnext = vin[rowb[0] - P + q * H + j];
+        Snext = vin[rowS + (q ^ ((R - 1) & 1)) * H + j];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = q ^ (r & 1);
+            side_next[r] = 0;
+            if (side_edge(r, qr)) side_next[r] = vin[side_addr(r, qr, 0)];
+        }
+    }
     for (int z = z0; z < z1; z++) {
         real U[R], side[R], fv[R];
+        real Nedge, Sedge;
         // lane j = 0 with q_r = 0 (x = 0, a boundary point that is never written) would read index -1:
         // it reads index M-1 of half 0 instead and the result is discarded
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int qr = q ^ (r & 1);
-            const int hq = qr * H, ho = (1 - qr) * H;
+            const int hq = qr * H;
             U[r] = vin[rowb[r] + sxy + hq + j];
-            if (ABL & 4) {
-                side[r] = c_cur[r];
-            } else {
-                // the side value is the "own" value of the neighbouring lane: wave shuffle instead of a second load;
-                // neighbour lane: j+1 when q_r = 1, j-1 when q_r = 0 (q_r is wave-uniform).  The wave's edge lane,
-                // and the last active lane (its neighbour j+1 = M-1 holds the boundary entry but has exited), load.
-                const real nb = qr ? __shfl_down(c_cur[r], 1, 64) : __shfl_up(c_cur[r], 1, 64);
-                const bool edge = qr ? (threadIdx.x == 63 || j == M - 2) : (threadIdx.x == 0);
-                side[r] = edge ? vin[rowb[r] + ho + j + (qr ? 1 : -1) + (qr | j ? 0 : M)] : nb;
-            }
             fv[r] = (ABL & 1) ? (real)1 : f[rowb[r] + hq + j];
         }
-        const real Nedge = (ABL & 4) ? c_cur[0] : vin[rowb[0] - P + q * H + j];
-        const real Sedge = (ABL & 4) ? c_cur[R - 1] : vin[rowb[R - 1] + P + (q ^ ((R - 1) & 1)) * H + j];
+        if (EARLY) {
+            Nedge = Nnext;
+            Sedge = Snext;
+            // plane z+1 (parities flipped); past the last plane of the chunk the values are not used, the loads stay
+            // inside the array (plane z1 <= sz-1 exists)
+            Nnext = vin[rowb[0] + sxy - P + (q ^ 1) * H + j];
+            rowS += sxy;
+            Snext = vin[rowS + (q ^ 1 ^ ((R - 1) & 1)) * H + j];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int qr = q ^ (r & 1);
+                const real nb = qr ? __shfl_down(c_cur[r], 1, 64) : __shfl_up(c_cur[r], 1, 64);
+                side[r] = side_edge(r, qr) ? side_next[r] : nb;
+                if (side_edge(r, qr ^ 1)) side_next[r] = vin[side_addr(r, qr ^ 1, sxy)];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int qr = q ^ (r & 1);
+                if (ABL & 4) {
+                    side[r] = c_cur[r];
+                } else {
+                    // the side value is the "own" value of the neighbouring lane: wave shuffle instead of a second load;
+                    // neighbour lane: j+1 when q_r = 1, j-1 when q_r = 0 (q_r is wave-uniform).  The wave's edge lane,
+                    // and the last active lane (its neighbour j+1 = M-1 holds the boundary entry but has exited), load.
+                    const real nb = qr ? __shfl_down(c_cur[r], 1, 64) : __shfl_up(c_cur[r], 1, 64);
+                    side[r] = side_edge(r, qr) ? vin[side_addr(r, qr, 0)] : nb;
+                }
+            }
+            Nedge = (ABL & 4) ? c_cur[0] : vin[rowb[0] - P + q * H + j];
+            Sedge = (ABL & 4) ? c_cur[R - 1] : vin[rowb[R - 1] + P + (q ^ ((R - 1) & 1)) * H + j];
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int qr = q ^ (r & 1);
@@ -183,6 +228,120 @@ __global__ void __launch_bounds__(64 * TYW)
             rowb[r] += sxy;
         }
         q ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------ relax, one colour, XSplit, edges through LDS
+// Same lane/row/plane assignment and the same per-point expression as relax3d_xs_kernel, but a workgroup is a
+// WX x WY arrangement of waves over an (x, y) tile of 64*WX pairs x R*WY rows, and the values a wave needs from
+// outside its own registers -- the "own" entries of the rows just above / below its R rows (N of row 0, S of row
+// R-1) and of the lanes next to lane 0 / lane 63 (the W or E "side" value) -- are handed over by the neighbouring
+// wave of the workgroup through LDS instead of being loaded again.  In relax3d_xs_kernel those re-loads are
+// (R+2)/R of the v stream plus one extra 128-byte line per row and wave edge, and the PMC counters show that most
+// of them miss in L2 (profiles/: FETCH_SIZE is 1.39x the v stream at R = 4).  Here only the rim of the workgroup
+// tile is loaded from memory.  One s_barrier per plane; the LDS slots are double-buffered by plane parity, so a
+// wave may run at most one plane ahead of its neighbours.  Every wave stays alive for the barriers: lanes past
+// the end of the row and waves past the last row are clamped onto valid entries and store nothing.
+template <class real, int WX, int WY, int R>
+__global__ void __launch_bounds__(64 * WX * WY)
+    relax3d_xs_lds_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
+                          int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
+                          int xcd_mode) {
+    __shared__ real ey[2][WY][WX][2][64];  // [slot][wy][wx][first / last row][lane]: c_cur of rows 0 and R-1
+    __shared__ real ex[2][WY][WX][2][R];   // [slot][wy][wx][lane 0 / lane 63][row]:  c_cur of the wave's edge lanes
+    const Geo<XSplit, real> g(sx, sy);
+    const int H = g.H;
+    const int M = (sx + 1) >> 1;
+    unsigned b = blockIdx.x;
+    if (xcd_mode == 1) {  // every XCD gets one contiguous run of the plain order (see relax3d_xs_kernel)
+        const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
+        b = k * per + (k < rem ? k : rem) + (b >> 3);
+    }
+    const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
+    const int lane = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int wx = w % WX, wy = w / WX;
+    const int jn = (bx * WX + wx) * 64 + lane;  // nominal pair index
+    const bool lane_on = jn < M - 1;            // x = 2j+q <= sx-2 needs j <= M-2
+    const int j = lane_on ? jn : M - 2;
+    const int y0 = 1 + (by * WY + wy) * R;
+    const int nrows = max(0, min(R, sy - 1 - y0));
+    const int z0 = zbeg + bz * zchunk;
+    const int z1 = min(z0 + zchunk, zend);
+    if (z0 >= z1) return;  // uniform over the workgroup
+    const size_t sxy = g.PL;
+    const int P = g.P;
+    size_t rowb[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) rowb[r] = g.row(min(y0 + r, sy - 1), z0);
+    int q = (colour + y0 + z0) & 1;
+    real c_prev[R], c_cur[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int qr = q ^ (r & 1);
+        c_prev[r] = vin[rowb[r] - sxy + qr * H + j];
+        c_cur[r] = vin[rowb[r] + (1 - qr) * H + j];
+    }
+    auto publish = [&](int slot, const real (&c)[R]) {
+        ey[slot][wy][wx][0][lane] = c[0];
+        ey[slot][wy][wx][1][lane] = c[R - 1];
+        if (lane == 0 || lane == 63) {
+#pragma unroll
+            for (int r = 0; r < R; r++) ex[slot][wy][wx][lane == 63][r] = c[r];
+        }
+    };
+    publish(z0 & 1, c_cur);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int z = z0; z < z1; z++) {
+        const int slot = z & 1;
+        real U[R], side[R], fv[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = q ^ (r & 1);
+            U[r] = vin[rowb[r] + sxy + qr * H + j];
+            fv[r] = f[rowb[r] + qr * H + j];
+        }
+        // N of row 0 / S of row R-1: from the wave above / below, or from memory on the rim of the tile
+        const real Nedge = wy > 0 ? ey[slot][wy - 1][wx][1][lane] : vin[rowb[0] - P + q * H + j];
+        const real Sedge = wy < WY - 1 ? ey[slot][wy + 1][wx][0][lane]
+                                       : vin[rowb[R - 1] + P + (q ^ ((R - 1) & 1)) * H + j];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = q ^ (r & 1);
+            const int ho = (1 - qr) * H;
+            // side value = "own" value of pair j+1 (q_r = 1) or j-1 (q_r = 0): the neighbouring lane, the neighbouring
+            // wave's edge lane (LDS), or memory (rim of the tile; pair M-1 holds only the boundary entry x = sx-1)
+            real nb;
+            if (qr) {
+                nb = __shfl_down(c_cur[r], 1, 64);
+                if (lane == 63 && wx < WX - 1) nb = ex[slot][wy][wx + 1][0][r];
+                if (jn == M - 2 || (lane == 63 && wx == WX - 1)) nb = vin[rowb[r] + ho + j + 1];
+            } else {
+                nb = __shfl_up(c_cur[r], 1, 64);
+                if (lane == 0 && wx > 0) nb = ex[slot][wy][wx - 1][1][r];
+                if (lane == 0 && wx == 0) nb = vin[rowb[r] + ho + j - 1 + (j ? 0 : M)];  // j = 0: x = 0, result discarded
+            }
+            side[r] = nb;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = q ^ (r & 1);
+            const real W = qr ? c_cur[r] : side[r];
+            const real E = qr ? side[r] : c_cur[r];
+            const real N = r == 0 ? Nedge : c_cur[r - 1];
+            const real S = r == R - 1 ? Sedge : c_cur[r + 1];
+            const real out = relax3d_point<real>(W, E, N, S, c_prev[r], U[r], fv[r], hx2, hy2, hz2);
+            if (lane_on && (qr | j) && r < nrows) __builtin_nontemporal_store(out, &vout[rowb[r] + qr * H + j]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            c_prev[r] = c_cur[r];
+            c_cur[r] = U[r];
+            rowb[r] += sxy;
+        }
+        q ^= 1;
+        publish(slot ^ 1, c_cur);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -377,7 +536,10 @@ __global__ void __launch_bounds__(256) interpolate3d_kernel(real* __restrict__ f
 // Slab form: pz = pzbeg + blockIdx.z is a GLOBAL coarse plane; the fine / coarse arrays start at global
 // planes fzoff / czoff (0 for whole grids).  The host passes only pz whose fine planes 2pz, 2pz+1 are
 // owned and interior-or-skipped (z = 0 is skipped here, z <= fz-2 follows from pz <= cz-2).
-template <class real, bool ADD>
+// COLOUR >= 0: only the fine points with (x + y + z) % 2 == COLOUR are written (the half-row of that parity in
+// every row).  The cycle uses COLOUR = 1 when a red-black sweep follows: the red pass overwrites every red interior
+// point from black neighbours only, so a corrected red value would never be read.
+template <class real, bool ADD, int COLOUR = -1>
 __global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict__ fine, int fx, int fy, int fzoff,
                                                                const real* __restrict__ coarse, int cx, int cy, int czoff,
                                                                int pzbeg) {
@@ -406,10 +568,14 @@ __global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict_
             const int y = 2 * py + dy;
             if (y < 1) continue;
             const size_t row = (size_t)y * gf.P + (size_t)(z - fzoff) * fxy;
-            const real e0 = interpolate3d_point<real>(0, dy, dz, get);
-            const real e1 = interpolate3d_point<real>(1, dy, dz, get);
-            if (i >= 1) fine[row + i] = ADD ? fine[row + i] + e0 : e0;   // x = 2i
-            fine[row + FH + i] = ADD ? fine[row + FH + i] + e1 : e1;     // x = 2i+1
+            if (COLOUR < 0 || ((COLOUR + dy + dz) & 1) == 0) {  // x = 2i
+                const real e0 = interpolate3d_point<real>(0, dy, dz, get);
+                if (i >= 1) fine[row + i] = ADD ? fine[row + i] + e0 : e0;
+            }
+            if (COLOUR < 0 || ((COLOUR + dy + dz) & 1) == 1) {  // x = 2i+1
+                const real e1 = interpolate3d_point<real>(1, dy, dz, get);
+                fine[row + FH + i] = ADD ? fine[row + FH + i] + e1 : e1;
+            }
         }
     }
 }
@@ -720,7 +886,7 @@ static void launch_xs(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int 
                            (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd); \
         return;
         switch (ctx->relax_ablate) {
-            MGX_ABL(1) MGX_ABL(2) MGX_ABL(3) MGX_ABL(4) MGX_ABL(5) MGX_ABL(7) MGX_ABL(8) MGX_ABL(12) MGX_ABL(15) MGX_ABL(16)
+            MGX_ABL(1) MGX_ABL(2) MGX_ABL(3) MGX_ABL(4) MGX_ABL(5) MGX_ABL(7) MGX_ABL(8) MGX_ABL(12) MGX_ABL(15) MGX_ABL(16) MGX_ABL(32)
             default: break;
         }
 #undef MGX_ABL
@@ -740,11 +906,50 @@ static void launch_xs_rows(mgx_ctx* ctx, real* v, const real* f, int sx, int sy,
     }
 }
 
+template <class real, int WX, int WY, int R>
+static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
+                          real hz2, int colour, int zchunk) {
+    const int M = (sx + 1) / 2;
+    const int gx = ceil_div(M - 1, 64 * WX), gy = ceil_div(sy - 2, WY * R), gz = ceil_div(zend - zbeg, zchunk);
+    hipLaunchKernelGGL((relax3d_xs_lds_kernel<real, WX, WY, R>), dim3((unsigned)gx * gy * gz), dim3(64, WX * WY, 1), 0,
+                       ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy,
+                       ctx->relax_xcd == 1 ? 1 : 0);
+}
+
+// LDS-exchange smoother: "relax3d.lds" = 100*WX + 10*WY + R picks the workgroup shape.  Returns false when the level is
+// too small for the shape (the caller falls back to relax3d_xs_kernel).
+template <class real>
+static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
+                                real hz2, int colour) {
+    const int code = ctx->relax_lds;
+    const int WX = code / 100, WY = (code / 10) % 10, R = code % 10;
+    const int M = (sx + 1) / 2;
+    if (M - 1 < 64 * WX || sy - 2 < WY * R) return false;
+    int zchunk = ctx->relax_zchunk;
+    if (zchunk <= 0) {
+        const long long tiles = (long long)ceil_div(M - 1, 64 * WX) * ceil_div(sy - 2, WY * R);
+        zchunk = 16;
+        while (zchunk > 2 && tiles * ceil_div(zend - zbeg, zchunk) * WX * WY < 32LL * ctx->num_cus) zchunk >>= 1;
+    }
+#define MGX_LDS(X, Y, RR)                                                                              \
+    case 100 * X + 10 * Y + RR:                                                                        \
+        launch_xs_lds<real, X, Y, RR>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk); \
+        return true;
+    switch (code) {
+        MGX_LDS(4, 2, 4) MGX_LDS(4, 4, 4) MGX_LDS(4, 4, 2) MGX_LDS(4, 2, 2) MGX_LDS(2, 4, 4) MGX_LDS(2, 2, 4) MGX_LDS(1, 4, 4)
+        MGX_LDS(1, 8, 4) MGX_LDS(2, 8, 2) MGX_LDS(2, 4, 2) MGX_LDS(4, 2, 8) MGX_LDS(2, 2, 8) MGX_LDS(8, 2, 4) MGX_LDS(8, 1, 4)
+        MGX_LDS(4, 1, 4) MGX_LDS(4, 1, 8)
+        default: return false;
+    }
+#undef MGX_LDS
+}
+
 // one colour pass over the local planes [zbeg, zend) of an x-split array with sx x sy rows
 template <class real>
 static void relax3d_xs_pass(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
                             real hz2, int colour) {
     if (zend <= zbeg || sx < 3 || sy < 3) return;
+    if (ctx->relax_lds > 0 && relax3d_xs_pass_lds<real>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour)) return;
     int ty = ctx->relax_ty, rows = ctx->relax_rows, zchunk = ctx->relax_zchunk;
     while (rows > 1 && rows * ty > sy - 2) rows >>= 1;  // small levels: do not idle most of a block
     while (ty > 1 && rows * ty > sy - 2) ty >>= 1;
@@ -887,21 +1092,31 @@ template <class real>
 static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real* f, const int n[3], real hx2, real hy2,
                                          real hz2, int mode, real* coarse_f, const int cn[3], int fzoff, int czoff, int pzbeg,
                                          int pzend) {
-    constexpr int CR = 2, TYW = 4;
     const Geo<XSplit, real> gc(cn[0], cn[1]);
     MGX_HIP(hipMemsetAsync(coarse_f + gc.PL * (size_t)(pzbeg - czoff), 0, gc.PL * (size_t)(pzend - pzbeg) * sizeof(real),
                            ctx->compute));
     if (cn[0] < 3 || cn[1] < 3) return MGX_OK;
-    const int gx = ceil_div(cn[0], 63), gy = ceil_div(cn[1] - 2, CR * TYW);
+    const int CRr = ctx->rr_cr == 1 ? 1 : 2, TYWr = ctx->rr_tyw == 8 ? 8 : (ctx->rr_tyw == 2 ? 2 : 4);
+    const int gx = ceil_div(cn[0], 63), gy = ceil_div(cn[1] - 2, CRr * TYWr);
     int pzchunk = ctx->rr_pzchunk > 0 ? ctx->rr_pzchunk : 8;
     while (pzchunk > 1 && (long long)gx * gy * ceil_div(pzend - pzbeg, pzchunk) < 4LL * ctx->num_cus) pzchunk >>= 1;
     dim3 g(gx, gy, ceil_div(pzend - pzbeg, pzchunk));
-    if (mode == MGX_RESIDUAL_REF_COMPAT)
-        hipLaunchKernelGGL((residual_restrict3d_xs_kernel<real, 0, CR, TYW>), g, dim3(64, TYW, 1), 0, ctx->compute, v, f, n[0],
-                           n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend);
-    else
-        hipLaunchKernelGGL((residual_restrict3d_xs_kernel<real, 1, CR, TYW>), g, dim3(64, TYW, 1), 0, ctx->compute, v, f, n[0],
-                           n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend);
+#define MGX_RR(M, C, W)                                                                                                  \
+    hipLaunchKernelGGL((residual_restrict3d_xs_kernel<real, M, C, W>), g, dim3(64, W, 1), 0, ctx->compute, v, f, n[0], n[1], \
+                       n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend)
+#define MGX_RR_W(M, C)                             \
+    do {                                           \
+        if (TYWr == 8) MGX_RR(M, C, 8);            \
+        else if (TYWr == 2) MGX_RR(M, C, 2);       \
+        else MGX_RR(M, C, 4);                      \
+    } while (0)
+    if (mode == MGX_RESIDUAL_REF_COMPAT) {
+        if (CRr == 1) MGX_RR_W(0, 1); else MGX_RR_W(0, 2);
+    } else {
+        if (CRr == 1) MGX_RR_W(1, 1); else MGX_RR_W(1, 2);
+    }
+#undef MGX_RR_W
+#undef MGX_RR
     return MGX_OK;
 }
 
@@ -1020,7 +1235,7 @@ int residual_restrict3d_slab(mgx_ctx* ctx, const real* v, const real* f, const i
 
 template <class real>
 int interpolate_correct3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff, const real* coarse_v, const int cn[3],
-                               int czoff, int pzbeg, int pzend) {
+                               int czoff, int pzbeg, int pzend, int colour) {
     MGX_REQUIRE(ctx && v && coarse_v, MGX_ERR_INVALID, "interpolate_correct_slab: NULL argument");
     int st = check_n3(n, "interpolate_correct_slab");
     if (st) return st;
@@ -1028,9 +1243,18 @@ int interpolate_correct3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff,
     if (st) return st;
     MGX_REQUIRE(pzbeg >= 0 && pzend <= cn[2] - 1 && pzbeg <= pzend && fzoff >= 0 && czoff >= 0 && czoff <= pzbeg, MGX_ERR_INVALID,
                 "interpolate_correct_slab: bad plane range");
+    MGX_REQUIRE(colour >= -1 && colour <= 1, MGX_ERR_INVALID, "interpolate_correct_slab: colour %d not in {-1, 0, 1}", colour);
     if (pzbeg == pzend) return MGX_OK;
-    hipLaunchKernelGGL((interpolate3d_xs_kernel<real, true>), grd((n[0] + 1) / 2 - 1, cn[1] - 1, pzend - pzbeg), blk(), 0,
-                       ctx->compute, v, n[0], n[1], fzoff, coarse_v, cn[0], cn[1], czoff, pzbeg);
+    const dim3 g = grd((n[0] + 1) / 2 - 1, cn[1] - 1, pzend - pzbeg);
+    if (colour < 0)
+        hipLaunchKernelGGL((interpolate3d_xs_kernel<real, true, -1>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
+                           cn[0], cn[1], czoff, pzbeg);
+    else if (colour == 0)
+        hipLaunchKernelGGL((interpolate3d_xs_kernel<real, true, 0>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
+                           cn[0], cn[1], czoff, pzbeg);
+    else
+        hipLaunchKernelGGL((interpolate3d_xs_kernel<real, true, 1>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
+                           cn[0], cn[1], czoff, pzbeg);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -1160,7 +1384,18 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
     int mgx3dxs_interpolate_correct_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff,                 \
                                                const real* coarse_v, const int cn[3], int czoff, int pzbeg,      \
                                                int pzend) {                                                      \
-        return mgx::interpolate_correct3d_slab<real>(ctx, v, n, fzoff, coarse_v, cn, czoff, pzbeg, pzend);       \
+        return mgx::interpolate_correct3d_slab<real>(ctx, v, n, fzoff, coarse_v, cn, czoff, pzbeg, pzend, -1);   \
+    }                                                                                                            \
+    int mgx3dxs_interpolate_correct_colour_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff,          \
+                                                      const real* coarse_v, const int cn[3], int czoff,          \
+                                                      int pzbeg, int pzend, int colour) {                        \
+        return mgx::interpolate_correct3d_slab<real>(ctx, v, n, fzoff, coarse_v, cn, czoff, pzbeg, pzend,        \
+                                                     colour);                                                    \
+    }                                                                                                            \
+    int mgx3dxs_interpolate_correct_colour_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,    \
+                                                 const int cn[3], int colour) {                                  \
+        return mgx::interpolate_correct3d_slab<real>(ctx, v, n, 0, coarse_v, cn, 0, 0, cn ? cn[2] - 1 : 0,       \
+                                                     colour);                                                    \
     }                                                                                                            \
     int mgx3dxs_pack_##SFX(mgx_ctx* ctx, const real* natural, real* xsplit, const int n[3]) {                    \
         return mgx::relayout3d<real, mgx::Natural, mgx::XSplit>(ctx, natural, xsplit, n);                        \
@@ -1197,6 +1432,12 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "relax3d.xcd")) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "relax3d.xcd must be 0, 1 or 2");
         ctx->relax_xcd = value;
+    } else if (!strcmp(name, "relax3d.lds")) {
+        ctx->relax_lds = value;  // 0 = relax3d_xs_kernel; 100*WX + 10*WY + R = relax3d_xs_lds_kernel<WX, WY, R>
+    } else if (!strcmp(name, "residual_restrict3d.cr")) {
+        ctx->rr_cr = value;   // coarse rows per lane of the streaming kernel: 1 or 2
+    } else if (!strcmp(name, "residual_restrict3d.tyw")) {
+        ctx->rr_tyw = value;  // waves per block: 2, 4 or 8
     } else if (!strcmp(name, "residual_restrict3d.stream")) {
         ctx->rr_stream = value ? 1 : 0;  // 1 = streaming shuffle kernel (x-split), 0 = LDS rolling-window kernel
     } else if (!strcmp(name, "residual_restrict3d.pzchunk")) {

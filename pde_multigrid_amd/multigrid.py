@@ -266,6 +266,13 @@ class _Ops3D(_Ops):
         cn = coarse_size(n)
         return self._run(ctx, [v, coarse], lambda a, c: fn(ctx._h, a, _ip(n), c, _ip(cn)), 0, _shape(n), dtype)
 
+    def interpolate_correct_colour(self, ctx, v, n, coarse, colour, dtype=None):
+        """x-split only: correct the points with (x+y+z) % 2 == colour (-1 = all)"""
+        dtype = dtype or v.dtype
+        fn, _ = self._fn("interpolate_correct_colour", dtype)
+        cn = coarse_size(n)
+        return self._run(ctx, [v, coarse], lambda a, c: fn(ctx._h, a, _ip(n), c, _ip(cn), C.c_int(colour)), 0, _shape(n), dtype)
+
     def jacobi(self, ctx, v, f, n, rng, omega, ncycles, dtype=None):
         dtype = dtype or v.dtype
         fn, ct = self._fn("jacobi", dtype)

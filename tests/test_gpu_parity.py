@@ -175,6 +175,63 @@ def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, rows, zchun
         ctx.set_param("relax3d.wave_planes", 0)
 
 
+@pytest.mark.parametrize("code", [424, 444, 442, 422, 244, 224, 144, 184, 282, 242, 428, 228, 824, 814, 414, 418])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_3d_xsplit_relax_lds_exchange_shapes(ctx, code, dtype):
+    """relax3d_xs_lds_kernel (edge rows / edge lanes handed over through LDS) == oracle for every workgroup shape,
+    on sizes where rows, lanes and planes do not fill the tile, with short and long z-chunks"""
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(code)
+    ctx.set_param("relax3d.lds", code)
+    try:
+        for n3 in ((129, 33, 17), (257, 65, 9), (513, 17, 9), (1025, 33, 5), (129, 129, 33)):
+            wx, wy, r = code // 100, (code // 10) % 10, code % 10
+            v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+            f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+            for zchunk in (0, 1, 3, 64):
+                ctx.set_param("relax3d.zchunk", zchunk)
+                assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 2), O.relax3d(n3, rg, v, f, 2, dtype=dtype)), (n3, zchunk)
+    finally:
+        ctx.set_param("relax3d.lds", 0)
+        ctx.set_param("relax3d.zchunk", 0)
+
+
+@pytest.mark.parametrize("abl", [16, 32])
+def test_3d_xsplit_relax_correct_ablation_variants(ctx, abl):
+    """the two A/B variants of relax3d_xs_kernel that keep the results exact: 16 = plain stores, 32 = edge rows /
+    edge lanes loaded one plane ahead"""
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(abl)
+    ctx.set_param("relax3d.ablate", abl)
+    try:
+        for n3 in ((129, 33, 17), (257, 65, 9), (65, 129, 33), (33, 17, 129)):
+            v = rng.uniform(-1, 1, O.shape(n3))
+            f = rng.uniform(-1, 1, O.shape(n3))
+            for zchunk in (0, 1, 3, 64):
+                ctx.set_param("relax3d.zchunk", zchunk)
+                assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 2), O.relax3d(n3, rg, v, f, 2, dtype=np.float64)), (n3, zchunk)
+    finally:
+        ctx.set_param("relax3d.ablate", 0)
+        ctx.set_param("relax3d.zchunk", 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n3", [(9, 9, 9), (17, 33, 9), (129, 17, 33)])
+def test_3d_xsplit_interpolate_correct_one_colour(ctx, dtype, n3):
+    """mgx3dxs_interpolate_correct_colour: the points of the colour get the reference's correction, the rest is untouched"""
+    rng = np.random.default_rng(11)
+    cn = P.coarse_size(n3)
+    v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    c = rng.uniform(-1, 1, O.shape(cn)).astype(dtype)
+    full = O.correct3d(n3, v, O.interpolate3d(n3, np.zeros(O.shape(n3), dtype), c, dtype=dtype), dtype=dtype)
+    z, y, x = np.meshgrid(*[np.arange(k) for k in n3[::-1]], indexing="ij")
+    par = (x + y + z) & 1
+    for colour in (0, 1):
+        got = P.ops3dxs.interpolate_correct_colour(ctx, v, n3, c, colour)
+        assert bits_equal(got, np.where(par == colour, full, v))
+    assert bits_equal(P.ops3dxs.interpolate_correct_colour(ctx, v, n3, c, -1), full)
+
+
 def test_3d_size_violations_return_status(ctx):
     v = np.zeros((9, 9, 9))
     with pytest.raises(P.MgxError) as e:  # reference: assert(csize == (fsize-1)/2+1)  N3/MultiGrid3D.cpp:60-62
