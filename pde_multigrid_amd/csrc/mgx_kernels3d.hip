@@ -345,6 +345,169 @@ __global__ void __launch_bounds__(64 * WX * WY)
     }
 }
 
+// ------------------------------------------------------------------ relax, one colour, XSplit, LDS edges + prefetch
+// relax3d_xs_lds_kernel with the streaming loads software-pipelined one plane ahead, so that the per-plane barrier
+// no longer exposes the load latency.  In step z (plane z) a wave
+//   1. issues the stores of plane z-1 (results are held one step in registers) and the loads of the NEXT step
+//      (U of plane z+2, f of plane z+1, rim values of plane z+1),
+//   2. publishes its edge entries of plane z+1 to the LDS slot (z+1)&1,
+//   3. reads the neighbours' edge entries of plane z from slot z&1 and computes plane z,
+//   4. meets the other waves at one s_barrier,
+//   5. waits for what it issued in 1 (explicit s_waitcnt vmcnt(0)) and renames the register sets.
+// Loads and stores therefore have the whole step (LDS traffic, ~40 fp64 operations per point, the barrier) to
+// complete, and a wave has memory requests in flight all the time instead of only while it waits for them.
+template <class real, int WX, int WY, int R>
+__global__ void __launch_bounds__(64 * WX * WY)
+    relax3d_xs_pipe_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
+                           int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
+                           int xcd_mode) {
+    __shared__ real ey[2][WY][WX][2][64];
+    __shared__ real ex[2][WY][WX][2][R];
+    const Geo<XSplit, real> g(sx, sy);
+    const int H = g.H;
+    const int M = (sx + 1) >> 1;
+    unsigned b = blockIdx.x;
+    if (xcd_mode == 1) {
+        const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
+        b = k * per + (k < rem ? k : rem) + (b >> 3);
+    }
+    const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
+    const int lane = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int wx = w % WX, wy = w / WX;
+    const int jn = (bx * WX + wx) * 64 + lane;
+    const bool lane_on = jn < M - 1;
+    const int j = lane_on ? jn : M - 2;
+    const int y0 = 1 + (by * WY + wy) * R;
+    const int nrows = max(0, min(R, sy - 1 - y0));
+    const int z0 = zbeg + bz * zchunk;
+    const int z1 = min(z0 + zchunk, zend);
+    if (z0 >= z1) return;
+    const int sxy = (int)g.PL;  // 32-bit offsets inside one plane pair; the plane base pointers below are 64-bit
+    const bool rimR = j == M - 2 || (lane == 63 && wx == WX - 1);  // E side (q_r = 1 rows) comes from memory
+    const bool rimL = lane == 0 && wx == 0;                         // W side (q_r = 0 rows) comes from memory
+    const int wyN = wy > 0 ? wy - 1 : 0, wyS = wy < WY - 1 ? wy + 1 : WY - 1;
+    const int wxL = wx > 0 ? wx - 1 : 0, wxR = wx < WX - 1 ? wx + 1 : WX - 1;
+    // uniform row offsets inside a plane (rows past sy-1 are clamped onto it: loads stay valid, nothing is stored)
+    int roff[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) roff[r] = min(y0 + r, sy - 1) * g.P;
+    const int roffN = (y0 - 1) * g.P, roffS = min(y0 + R, sy - 1) * g.P;
+    // plane z of the arrays (uniform 64-bit pointers, advanced by one plane per step)
+    const real* pv = vin + (size_t)z0 * g.PL;
+    const real* pf = f + (size_t)z0 * g.PL;
+    real* po = vout + (size_t)z0 * g.PL;
+    int q = (colour + y0 + z0) & 1;
+    real cp[R], cc[R], cu[R], cn[R], fc[R], fn[R], xc[R], xn[R], oc[R], op[R];
+    real Nc = 0, Sc = 0, Nn = 0, Sn = 0;
+
+    // everything that comes from memory besides the column itself, for the plane at offset dz from pv, row parity qq.
+    // rim-right lanes need index j+1 of half 0 in q_r = 1 rows, rim-left lanes index j-1 of half 1 in q_r = 0 rows
+    // (j = 0: x = 0, the result is discarded, index M-1 keeps the load inside the array); in the other rows the lane
+    // re-loads its own entry (a cache hit) and the value is not used.  (A macro, not a lambda: scalars handed to a
+    // lambda by reference end up in scratch memory here.)
+#define MGX_LOAD_RIM(dz, qq, X, Nv, Sv)                                                        \
+    do {                                                                                       \
+        const real* p_ = pv + (dz) * sxy;                                                      \
+        if (wy == 0) Nv = p_[roffN + (qq) * H + j];                                            \
+        if (wy == WY - 1) Sv = p_[roffS + ((qq) ^ ((R - 1) & 1)) * H + j];                     \
+        if (rimL || rimR) {                                                                    \
+            _Pragma("unroll") for (int r = 0; r < R; r++) {                                    \
+                const int qr_ = (qq) ^ (r & 1);                                                \
+                const int d_ = qr_ ? (rimR ? 1 : 0) : (rimL ? (j ? -1 : M - 1) : 0);           \
+                X[r] = p_[roff[r] + (1 - qr_) * H + j + d_];                                   \
+            }                                                                                  \
+        }                                                                                      \
+    } while (0)
+    auto publish = [&](int slot, const real (&c)[R]) __attribute__((always_inline)) {
+        ey[slot][wy][wx][0][lane] = c[0];
+        ey[slot][wy][wx][1][lane] = c[R - 1];
+        if (lane == 0 || lane == 63) {
+#pragma unroll
+            for (int r = 0; r < R; r++) ex[slot][wy][wx][lane == 63][r] = c[r];
+        }
+    };
+    auto store_plane = [&](int dz, int qq, const real (&O)[R]) __attribute__((always_inline)) {
+        real* p = po + dz * sxy;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = qq ^ (r & 1);
+            if (lane_on && (qr | j) && r < nrows) __builtin_nontemporal_store(O[r], &p[roff[r] + qr * H + j]);
+        }
+    };
+
+    // prologue: planes z0-1, z0, z0+1 of the column, f and rim of plane z0
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int qr = q ^ (r & 1);
+        cp[r] = pv[roff[r] - sxy + qr * H + j];
+        cc[r] = pv[roff[r] + (1 - qr) * H + j];
+        cu[r] = pv[roff[r] + sxy + qr * H + j];
+        fc[r] = pf[roff[r] + qr * H + j];
+        xc[r] = xn[r] = 0;
+        op[r] = 0;
+    }
+    MGX_LOAD_RIM(0, q, xc, Nc, Sc);
+    publish(z0 & 1, cc);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int z = z0; z < z1; z++) {
+        const bool more = z + 1 < z1;
+        if (z > z0) store_plane(-1, q ^ 1, op);  // results of plane z-1
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int qn = q ^ 1 ^ (r & 1);  // row parity in plane z+1
+                cn[r] = pv[roff[r] + 2 * sxy + qn * H + j];
+                fn[r] = pf[roff[r] + sxy + qn * H + j];
+            }
+            MGX_LOAD_RIM(1, q ^ 1, xn, Nn, Sn);
+            publish((z + 1) & 1, cu);
+        }
+        const int slot = z & 1;
+        const real Nl = ey[slot][wyN][wx][1][lane], Sl = ey[slot][wyS][wx][0][lane];
+        const real Nedge = wy > 0 ? Nl : Nc;
+        const real Sedge = wy < WY - 1 ? Sl : Sc;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = q ^ (r & 1);
+            const real fromR = ex[slot][wy][wxR][0][r], fromL = ex[slot][wy][wxL][1][r];
+            real nb = qr ? __shfl_down(cc[r], 1, 64) : __shfl_up(cc[r], 1, 64);
+            if (qr) {
+                if (lane == 63) nb = fromR;
+                if (rimR) nb = xc[r];
+            } else {
+                if (lane == 0) nb = fromL;
+                if (rimL) nb = xc[r];
+            }
+            const real W = qr ? cc[r] : nb;
+            const real E = qr ? nb : cc[r];
+            const real N = r == 0 ? Nedge : cc[r - 1];
+            const real S = r == R - 1 ? Sedge : cc[r + 1];
+            oc[r] = relax3d_point<real>(W, E, N, S, cp[r], cu[r], fc[r], hx2, hy2, hz2);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this step's prefetch and stores have had the whole step
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            cp[r] = cc[r];
+            cc[r] = cu[r];
+            cu[r] = cn[r];
+            fc[r] = fn[r];
+            xc[r] = xn[r];
+            op[r] = oc[r];
+        }
+        Nc = Nn;
+        Sc = Sn;
+        pv += sxy;
+        pf += sxy;
+        po += sxy;
+        q ^= 1;
+    }
+    store_plane(-1, q ^ 1, op);  // the last plane
+#undef MGX_LOAD_RIM
+}
+
 // ------------------------------------------------------------------ relax, whole small level in one workgroup
 // Levels up to 17^3 (<= 4913 points) are pure launch latency with one launch per colour pass (about 5 us each;
 // the thesis runs 3000 sweeps per level).  Here ONE workgroup keeps v and f of the whole level in LDS (2 x 38 KB
@@ -911,9 +1074,14 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
                           real hz2, int colour, int zchunk) {
     const int M = (sx + 1) / 2;
     const int gx = ceil_div(M - 1, 64 * WX), gy = ceil_div(sy - 2, WY * R), gz = ceil_div(zend - zbeg, zchunk);
-    hipLaunchKernelGGL((relax3d_xs_lds_kernel<real, WX, WY, R>), dim3((unsigned)gx * gy * gz), dim3(64, WX * WY, 1), 0,
-                       ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy,
-                       ctx->relax_xcd == 1 ? 1 : 0);
+    if (ctx->relax_lds >= 1000)
+        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, WX, WY, R>), dim3((unsigned)gx * gy * gz), dim3(64, WX * WY, 1), 0,
+                           ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy,
+                           ctx->relax_xcd == 1 ? 1 : 0);
+    else
+        hipLaunchKernelGGL((relax3d_xs_lds_kernel<real, WX, WY, R>), dim3((unsigned)gx * gy * gz), dim3(64, WX * WY, 1), 0,
+                           ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy,
+                           ctx->relax_xcd == 1 ? 1 : 0);
 }
 
 // LDS-exchange smoother: "relax3d.lds" = 100*WX + 10*WY + R picks the workgroup shape.  Returns false when the level is
@@ -921,7 +1089,7 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
 template <class real>
 static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
                                 real hz2, int colour) {
-    const int code = ctx->relax_lds;
+    const int code = ctx->relax_lds % 1000;  // + 1000: the software-pipelined kernel (relax3d_xs_pipe_kernel)
     const int WX = code / 100, WY = (code / 10) % 10, R = code % 10;
     const int M = (sx + 1) / 2;
     if (M - 1 < 64 * WX || sy - 2 < WY * R) return false;

@@ -175,17 +175,18 @@ def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, rows, zchun
         ctx.set_param("relax3d.wave_planes", 0)
 
 
-@pytest.mark.parametrize("code", [424, 444, 442, 422, 244, 224, 144, 184, 282, 242, 428, 228, 824, 814, 414, 418])
+@pytest.mark.parametrize("code", [424, 444, 442, 422, 244, 224, 144, 184, 282, 242, 428, 228, 824, 814, 414, 418,
+                                  1424, 1444, 1442, 1422, 1244, 1224, 1144, 1184, 1282, 1242, 1428, 1228, 1824, 1814, 1414, 1418])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_3d_xsplit_relax_lds_exchange_shapes(ctx, code, dtype):
-    """relax3d_xs_lds_kernel (edge rows / edge lanes handed over through LDS) == oracle for every workgroup shape,
-    on sizes where rows, lanes and planes do not fill the tile, with short and long z-chunks"""
+    """relax3d_xs_lds_kernel (edge rows / edge lanes handed over through LDS) and relax3d_xs_pipe_kernel (code + 1000:
+    the same with the loads one plane ahead and the stores one plane behind) == oracle for every workgroup shape, on
+    sizes where rows, lanes and planes do not fill the tile, with short and long z-chunks"""
     rg = [-1, 1, 0, 2, 0.5, 3]
     rng = np.random.default_rng(code)
     ctx.set_param("relax3d.lds", code)
     try:
         for n3 in ((129, 33, 17), (257, 65, 9), (513, 17, 9), (1025, 33, 5), (129, 129, 33)):
-            wx, wy, r = code // 100, (code // 10) % 10, code % 10
             v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
             f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
             for zchunk in (0, 1, 3, 64):
