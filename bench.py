@@ -134,7 +134,7 @@ def main():
         ctx.record(e1)
         args.smoother_sweeps = (args.smoother_sweeps // max(args.v1, 1)) * max(args.v1, 1)
         my_lups_per_launch = (n - 2) ** 3 / 2.0
-        kname = "relax3d_xs_kernel<%s> (finest level, x-split layout, one colour per launch)"
+        kname = "relax3d_xs_pipe_kernel<%s,2,8,2> (finest level, x-split layout, one colour per launch)"
     else:
         for c in (0, 1):
             mg.relax_colour_local(0, c)
@@ -146,7 +146,7 @@ def main():
         ctx.record(e1)
         p = mg.plan(0)
         my_lups_per_launch = (n - 2) ** 2 * (p.uend - p.ubeg) / 2.0
-        kname = "relax3d_xs_kernel<%s> (finest level, rank 0's z-slab, one colour per launch, ghost exchange excluded)"
+        kname = "relax3d_xs_pipe_kernel<%s,2,8,2> (finest level, rank 0's z-slab, one colour per launch, ghost exchange excluded)"
     ms = ctx.elapsed_ms(e0, e1)
     launches = 2 * args.smoother_sweeps  # one launch per colour
     bytes_per_launch = 3 * wbytes * my_lups_per_launch  # 24 B/LUP fp64 per red+black sweep, half the points per colour launch
@@ -198,7 +198,7 @@ def main():
             # HBM bytes per launch of the same kernel from the separate rocprofv3 --pmc passes (tools/pmc_summary.py):
             # 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md
             with open(pmc) as fh:
-                out["roofline"]["traffic"] = json.load(fh).get("relax3d_xs_kernel_f64_513_bytes_per_launch")
+                out["roofline"]["traffic"] = json.load(fh).get("smoother_f64_513_bytes_per_launch")
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as O  # CPU baseline leg only: the checker timed as a reported baseline

@@ -22,7 +22,7 @@ struct mgx_ctx {
     int relax_small = 1;   // levels <= 17^3: all sweeps of a Relax call in one workgroup (LDS resident)
     int relax_ablate = 0;  // diagnostic kernel variants (tools only)
     int rr_stream = 1;     // x-split residual+restrict: streaming shuffle kernel (1) or LDS window kernel (0)
-    int relax_lds = 0;  // LDS-exchange smoother shape code (0 = off), see relax3d_xs_pass_lds
+    int relax_lds = -1;  // smoother kernel choice: -1 automatic, 0 relax3d_xs_kernel, shape codes see relax3d_xs_pass_lds
     int rr_cr = 2, rr_tyw = 4;  // streaming residual+restrict: coarse rows per lane, waves per block
     int rr_pzchunk = 0;    // coarse planes per block of residual_restrict3d_kernel, 0 = automatic
     void* scratch = nullptr;  // small device workspace (reductions, tables)

@@ -1089,16 +1089,42 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
 template <class real>
 static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
                                 real hz2, int colour) {
-    const int code = ctx->relax_lds % 1000;  // + 1000: the software-pipelined kernel (relax3d_xs_pipe_kernel)
-    const int WX = code / 100, WY = (code / 10) % 10, R = code % 10;
     const int M = (sx + 1) / 2;
-    if (M - 1 < 64 * WX || sy - 2 < WY * R) return false;
     int zchunk = ctx->relax_zchunk;
+    int code = ctx->relax_lds;
+    const int prev = ctx->relax_lds;
+    if (code < 0) {
+        // automatic (the default).  Measured on MI355X (tools/sweep_pipe.py, profiles/r01_sweep_pipe_*.txt): the
+        // pipelined kernel with 2 x 8 waves of 2 rows wins from 257^3 up when the launch is ONE resident round of
+        // workgroups -- about one 16-wave workgroup per CU, each streaming a long run of planes (fp32 moves half the
+        // bytes per wave and wants 8 x as many, shorter runs); below 257^2 rows, or for runs of a few planes (the
+        // edge planes of a z-slab), relax3d_xs_kernel is faster.
+        if (M - 1 < 128 || sy - 2 < 64 || zend - zbeg < 8) return false;
+        code = 1282;
+        if (zchunk <= 0) {
+            const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, 16);
+            const int target = ctx->num_cus * (sizeof(real) == 4 ? 8 : 1);
+            const int nchunks = max(1, (target + tiles / 2) / tiles);
+            zchunk = max(8, ceil_div(zend - zbeg, nchunks));
+        }
+        ctx->relax_lds = code;  // launch_xs_lds picks the pipelined kernel from it
+    }
+    code %= 1000;  // + 1000: the software-pipelined kernel (relax3d_xs_pipe_kernel)
+    const int WX = code / 100, WY = (code / 10) % 10, R = code % 10;
+    if (M - 1 < 64 * WX || sy - 2 < WY * R) {
+        ctx->relax_lds = prev;
+        return false;
+    }
     if (zchunk <= 0) {
         const long long tiles = (long long)ceil_div(M - 1, 64 * WX) * ceil_div(sy - 2, WY * R);
         zchunk = 16;
         while (zchunk > 2 && tiles * ceil_div(zend - zbeg, zchunk) * WX * WY < 32LL * ctx->num_cus) zchunk >>= 1;
     }
+    struct Restore {  // the launch below reads ctx->relax_lds; put the user's setting back on every path
+        mgx_ctx* c;
+        int v;
+        ~Restore() { c->relax_lds = v; }
+    } restore{ctx, prev};
 #define MGX_LDS(X, Y, RR)                                                                              \
     case 100 * X + 10 * Y + RR:                                                                        \
         launch_xs_lds<real, X, Y, RR>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk); \
@@ -1117,7 +1143,7 @@ template <class real>
 static void relax3d_xs_pass(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
                             real hz2, int colour) {
     if (zend <= zbeg || sx < 3 || sy < 3) return;
-    if (ctx->relax_lds > 0 && relax3d_xs_pass_lds<real>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour)) return;
+    if (ctx->relax_lds != 0 && relax3d_xs_pass_lds<real>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour)) return;
     int ty = ctx->relax_ty, rows = ctx->relax_rows, zchunk = ctx->relax_zchunk;
     while (rows > 1 && rows * ty > sy - 2) rows >>= 1;  // small levels: do not idle most of a block
     while (ty > 1 && rows * ty > sy - 2) ty >>= 1;
@@ -1601,7 +1627,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "relax3d.xcd must be 0, 1 or 2");
         ctx->relax_xcd = value;
     } else if (!strcmp(name, "relax3d.lds")) {
-        ctx->relax_lds = value;  // 0 = relax3d_xs_kernel; 100*WX + 10*WY + R = relax3d_xs_lds_kernel<WX, WY, R>
+        ctx->relax_lds = value;  // -1 = automatic (default), 0 = relax3d_xs_kernel, 100*WX + 10*WY + R = relax3d_xs_lds_kernel<WX, WY, R>,
+                                 // 1000 + that = relax3d_xs_pipe_kernel<WX, WY, R>
     } else if (!strcmp(name, "residual_restrict3d.cr")) {
         ctx->rr_cr = value;   // coarse rows per lane of the streaming kernel: 1 or 2
     } else if (!strcmp(name, "residual_restrict3d.tyw")) {

@@ -193,7 +193,7 @@ def test_3d_xsplit_relax_lds_exchange_shapes(ctx, code, dtype):
                 ctx.set_param("relax3d.zchunk", zchunk)
                 assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 2), O.relax3d(n3, rg, v, f, 2, dtype=dtype)), (n3, zchunk)
     finally:
-        ctx.set_param("relax3d.lds", 0)
+        ctx.set_param("relax3d.lds", -1)
         ctx.set_param("relax3d.zchunk", 0)
 
 
@@ -204,6 +204,7 @@ def test_3d_xsplit_relax_correct_ablation_variants(ctx, abl):
     rg = [-1, 1, 0, 2, 0.5, 3]
     rng = np.random.default_rng(abl)
     ctx.set_param("relax3d.ablate", abl)
+    ctx.set_param("relax3d.lds", 0)  # relax3d_xs_kernel, whatever the automatic choice would be
     try:
         for n3 in ((129, 33, 17), (257, 65, 9), (65, 129, 33), (33, 17, 129)):
             v = rng.uniform(-1, 1, O.shape(n3))
@@ -213,6 +214,7 @@ def test_3d_xsplit_relax_correct_ablation_variants(ctx, abl):
                 assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 2), O.relax3d(n3, rg, v, f, 2, dtype=np.float64)), (n3, zchunk)
     finally:
         ctx.set_param("relax3d.ablate", 0)
+        ctx.set_param("relax3d.lds", -1)
         ctx.set_param("relax3d.zchunk", 0)
 
 
@@ -231,6 +233,17 @@ def test_3d_xsplit_interpolate_correct_one_colour(ctx, dtype, n3):
         got = P.ops3dxs.interpolate_correct_colour(ctx, v, n3, c, colour)
         assert bits_equal(got, np.where(par == colour, full, v))
     assert bits_equal(P.ops3dxs.interpolate_correct_colour(ctx, v, n3, c, -1), full)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n3", [(257, 129, 33), (513, 129, 17), (257, 257, 12 + 5), (1025, 129, 9)])
+def test_3d_xsplit_relax_default_kernel_choice_large_rows(ctx, dtype, n3):
+    """default parameters on levels wide enough for the automatic choice of the pipelined LDS-exchange smoother"""
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(3)
+    v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 2), O.relax3d(n3, rg, v, f, 2, dtype=dtype))
 
 
 def test_3d_size_violations_return_status(ctx):

@@ -50,15 +50,25 @@ def main():
             continue
         if name not in best or grid > best[name]:
             best[name] = grid
+    def upper(vals):
+        """levels that are launched with the same grid (one workgroup per CU) share a key: keep the finest level's
+        dispatches = the upper cluster when the values are clearly bimodal"""
+        lo, hi = min(vals), max(vals)
+        if lo <= 0 or hi <= 3 * lo:
+            return vals
+        cut = (lo * hi) ** 0.5
+        return [v for v in vals if v >= cut]
+
     out = {}
     for name, grid in sorted(best.items()):
         key = (name, grid)
         e = {"grid_size": grid}
         if durations.get(key):
-            ds = durations[key]
+            ds = upper(durations[key])
             e["dispatches"] = len(ds)
             e["avg_duration_us"] = round(sum(ds) / len(ds) / 1e3, 2)
         for cname, vals in counters.get(key, {}).items():
+            vals = upper(vals)
             e[cname] = round(sum(vals) / len(vals), 2)
         if "FETCH_SIZE" in e:
             e["hbm_read_bytes_per_launch"] = 2 * e["FETCH_SIZE"] * 1024

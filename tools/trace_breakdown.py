@@ -17,6 +17,13 @@ for path in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=Tru
     rows += list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[skip:]
+# the pipelined smoother is launched with one workgroup per CU on every large level, so dispatches of different
+# levels share a grid size: split such a group where its durations are clearly bimodal
+byk = collections.defaultdict(list)
+for r in rows:
+    grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+    byk[(r["Kernel_Name"], grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+cut = {k: (min(v) * max(v)) ** 0.5 for k, v in byk.items() if max(v) > 3 * min(v)}
 agg = collections.OrderedDict()
 busy = 0
 gaps = 0
@@ -25,6 +32,9 @@ for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
     name = r["Kernel_Name"].replace("void mgx::", "").split("(")[0][:60]
+    c = cut.get((r["Kernel_Name"], grid))
+    if c:
+        name = name[:52] + (" [long]" if e - s >= c else " [short]")
     k = (name, grid)
     a = agg.setdefault(k, [0, 0])
     a[0] += 1
