@@ -989,6 +989,195 @@ __global__ void __launch_bounds__(64 * TYW)
     }
 }
 
+// ------------------------------------------------------------------ residual + restrict, streaming, rows shared in LDS
+// residual_restrict3d_xs_kernel re-reads three of a lane's seven fine rows of v (and one of its five rows of f) that
+// the next row group also reads, and the PMC counters show those re-reads all reach the fabric (3.76 GB for 2.16 GB
+// of v and f at 513^3).  Here the TYW waves of a workgroup (adjacent row groups) load only the four rows they own;
+// rows 4..6 of v and rows 4..5 of f come from the wave below through LDS (the last wave of the workgroup loads
+// them).  Same software pipeline as relax3d_xs_pipe_kernel: in the step of fine plane g a wave takes delivery of
+// what it requested a step earlier (its rows of v at plane g+1 and of f at plane g), requests plane g+2 / g+1,
+// publishes, meets the other waves at ONE barrier, reads the neighbour's rows and computes the residual of plane g.
+// Lanes 0 and 63 are halo lanes (they supply the x-1 residuals of lane 1 and the x+1 value of lane 62): a wave
+// produces 62 coarse columns and no lane loads anything but its own column.  Per-point expressions and the
+// association of the 27-point sum are those of residual_restrict3d_xs_kernel.
+template <class real, int MODE, int TYW>
+__global__ void __launch_bounds__(64 * TYW)
+    residual_restrict3d_xs_pipe_kernel(const real* __restrict__ v, const real* __restrict__ f, int sx, int sy, int szg,
+                                       real hx2, real hy2, real hz2, real* __restrict__ coarse, int cx, int cy, int czg,
+                                       int pzchunk, int fzoff, int czoff, int pzbeg, int pzend) {
+    constexpr int CR = 2, NR = 7, OWN = 4;
+    __shared__ real sv[2][TYW][3][2][64];  // [slot][wave][row 0..2][A / B][lane]: v of plane g+1
+    __shared__ real sf[2][TYW][2][2][64];  // [slot][wave][row 0..1][A / B][lane]: f of plane g
+    const Geo<XSplit, real> gf(sx, sy), gc(cx, cy);
+    const int lane = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int in = blockIdx.x * 62 + lane;  // nominal coarse column; lanes past the row are clamped and masked
+    const int i = min(in, cx - 1);
+    const int cyb = 1 + (blockIdx.y * TYW + w) * CR;
+    const bool wave_on = cyb <= cy - 2;                       // waves past the last coarse row only keep the barriers company
+    const bool lastw = w == TYW - 1 || cyb + CR > cy - 2;     // no active wave below in this workgroup
+    int pz0 = pzbeg + blockIdx.z * pzchunk;
+    const int pz1 = min(min(pz0 + pzchunk, pzend), czg - 1);
+    if (pz0 < 1) pz0 = 1;
+    if (pz0 >= pz1) return;  // uniform over the workgroup
+    const bool hasB = i <= cx - 2;                            // the odd-x entry 2i+1 exists
+    const bool xinA = in >= 1 && in <= cx - 2;                // x = 2i is interior (and the lane is inside the row)
+    const bool validB = in <= cx - 2 && lane < 63;            // lane 63 has no x+1 neighbour: its B residual is not used
+    const bool produces = xinA && lane >= 1 && lane <= 62 && wave_on;
+    const int yf0 = 2 * cyb - 2;
+    int roff[NR];
+    bool yin[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int y = yf0 + r;
+        roff[r] = min(y, sy - 1) * gf.P;
+        yin[r] = y >= 1 && y <= sy - 2;
+    }
+    const int PL = (int)gf.PL;
+    const int offA = i, offB = gf.H + (hasB ? i : 0);
+    // residuals of fine plane g on rows 1 .. 5 for x = 2i (rA) and x = 2i+1 (rB); 0 outside the interior
+    auto resid = [&](const real (&AP)[NR], const real (&BP)[NR], const real (&AC)[NR], const real (&BC)[NR],
+                     const real (&AN)[NR], const real (&BN)[NR], const real (&fA)[NR], const real (&fB)[NR],
+                     real (&rA)[NR - 2], real (&rB)[NR - 2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 1; r < NR - 1; r++) {
+            const real Bl = __shfl_up(BC[r], 1, 64);    // v(2i-1): odd entry of lane i-1
+            const real Ar = __shfl_down(AC[r], 1, 64);  // v(2i+2): even entry of lane i+1
+            const real a = residual3d_point<real, MODE>(Bl, BC[r], AC[r - 1], AC[r + 1], AP[r], AN[r], AC[r], fA[r], hx2, hy2, hz2);
+            const real b = residual3d_point<real, MODE>(AC[r], Ar, BC[r - 1], BC[r + 1], BP[r], BN[r], BC[r], fB[r], hx2, hy2, hz2);
+            rA[r - 1] = (yin[r] && xinA && lane > 0) ? a : (real)0;
+            rB[r - 1] = (yin[r] && validB) ? b : (real)0;
+        }
+    };
+    real AP[NR], BP[NR], AC[NR], BC[NR], AN[NR], BN[NR], AX[NR], BX[NR], fA[NR], fB[NR], fAX[OWN], fBX[OWN];
+    real rAm[NR - 2], rBm[NR - 2], rA0[NR - 2], rB0[NR - 2], rAp[NR - 2], rBp[NR - 2];
+    // prologue (no sharing yet): v planes 2pz0-2, 2pz0-1, 2pz0 and f of plane 2pz0-1 on all rows, residual of 2pz0-1
+    {
+        const real* p0 = v + (size_t)(2 * pz0 - 2 - fzoff) * gf.PL;
+        const real* q1 = f + (size_t)(2 * pz0 - 1 - fzoff) * gf.PL;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            AP[r] = p0[roff[r] + offA];
+            BP[r] = p0[roff[r] + offB];
+            AC[r] = p0[PL + roff[r] + offA];
+            BC[r] = p0[PL + roff[r] + offB];
+            AN[r] = p0[2 * PL + roff[r] + offA];
+            BN[r] = p0[2 * PL + roff[r] + offB];
+            fA[r] = q1[roff[r] + offA];
+            fB[r] = q1[roff[r] + offB];
+            AX[r] = BX[r] = 0;
+        }
+        resid(AP, BP, AC, BC, AN, BN, fA, fB, rAm, rBm);
+#pragma unroll
+        for (int r = 0; r < NR; r++) { AP[r] = AC[r]; BP[r] = BC[r]; AC[r] = AN[r]; BC[r] = BN[r]; }
+    }
+    // plane pointers of the next requests: v at plane gq+1, f at plane gq, gq = the plane of the coming step
+    const real* pvn = v + (size_t)(2 * pz0 + 1 - fzoff) * gf.PL;
+    const real* pfn = f + (size_t)(2 * pz0 - fzoff) * gf.PL;
+    auto request = [&]() __attribute__((always_inline)) {  // own rows (and the shared rows, for the last wave) of v / f
+#pragma unroll
+        for (int r = 0; r < OWN; r++) {
+            AX[r] = pvn[roff[r] + offA];
+            BX[r] = pvn[roff[r] + offB];
+            fAX[r] = pfn[roff[r] + offA];
+            fBX[r] = pfn[roff[r] + offB];
+        }
+        if (lastw) {
+#pragma unroll
+            for (int r = OWN; r < NR; r++) {
+                AX[r] = pvn[roff[r] + offA];
+                BX[r] = pvn[roff[r] + offB];
+            }
+            // f rows 4, 5 travel in the slots of v rows that are not needed above the residual rows: AX/BX have no
+            // row 7, so they get their own two registers
+        }
+        pvn += PL;
+        pfn += PL;
+    };
+    real fA45[2], fB45[2], fAX45[2] = {0, 0}, fBX45[2] = {0, 0};
+    auto request_f45 = [&](const real* pf_plane) __attribute__((always_inline)) {
+        if (lastw) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                fAX45[k] = pf_plane[roff[OWN + k] + offA];
+                fBX45[k] = pf_plane[roff[OWN + k] + offB];
+            }
+        }
+    };
+    // one fine plane: on entry AP / AC hold planes g-1 / g, AX + fAX what was requested for g+1 / g
+    auto step = [&](bool more, real (&rA)[NR - 2], real (&rB)[NR - 2], int g) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the requests of the previous step
+#pragma unroll
+        for (int r = 0; r < NR; r++) { AN[r] = AX[r]; BN[r] = BX[r]; }
+#pragma unroll
+        for (int r = 0; r < OWN; r++) { fA[r] = fAX[r]; fB[r] = fBX[r]; }
+        fA45[0] = fAX45[0]; fA45[1] = fAX45[1]; fB45[0] = fBX45[0]; fB45[1] = fBX45[1];
+        if (more) {
+            request_f45(pfn);
+            request();
+        }
+        const int slot = g & 1;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            sv[slot][w][r][0][lane] = AN[r];
+            sv[slot][w][r][1][lane] = BN[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            sf[slot][w][r][0][lane] = fA[r];
+            sf[slot][w][r][1][lane] = fB[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!lastw) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                AN[OWN + r] = sv[slot][w + 1][r][0][lane];
+                BN[OWN + r] = sv[slot][w + 1][r][1][lane];
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                fA[OWN + r] = sf[slot][w + 1][r][0][lane];
+                fB[OWN + r] = sf[slot][w + 1][r][1][lane];
+            }
+        } else {
+            fA[OWN] = fA45[0]; fA[OWN + 1] = fA45[1]; fB[OWN] = fB45[0]; fB[OWN + 1] = fB45[1];
+        }
+        fA[NR - 1] = fB[NR - 1] = 0;  // row 6 has no residual
+        resid(AP, BP, AC, BC, AN, BN, fA, fB, rA, rB);
+#pragma unroll
+        for (int r = 0; r < NR; r++) { AP[r] = AC[r]; BP[r] = BC[r]; AC[r] = AN[r]; BC[r] = BN[r]; }
+    };
+    request_f45(pfn);
+    request();
+    for (int pz = pz0; pz < pz1; pz++) {
+        step(true, rA0, rB0, 2 * pz);                  // plane 2pz (requests plane 2pz+2 of v, 2pz+1 of f)
+        step(pz + 1 < pz1, rAp, rBp, 2 * pz + 1);      // plane 2pz+1
+        // per-row sub-sums a, b, c of residual rows 0 .. 4 (x-1 values: rB of lane i-1)
+        real sa[NR - 2], sb[NR - 2], sc[NR - 2];
+#pragma unroll
+        for (int r = 0; r < NR - 2; r++) {
+            const real lm = __shfl_up(rBm[r], 1, 64), l0 = __shfl_up(rB0[r], 1, 64), lp = __shfl_up(rBp[r], 1, 64);
+            sa[r] = rA0[r];
+            sb[r] = ((rAp[r] + rB0[r]) + rAm[r]) + l0;      // (N + E + S + O): (x,z+1), (x+1,z), (x,z-1), (x-1,z)
+            sc[r] = ((rBp[r] + rBm[r]) + lm) + lp;          // (NE + SE + SO + NO)
+        }
+        if (produces) {
+#pragma unroll
+            for (int c = 0; c < CR; c++) {
+                const int py = cyb + c;
+                if (py <= cy - 2) {
+                    const int rn = 2 * c, rc = 2 * c + 1, rs = 2 * c + 2;
+                    coarse[gc.row(py, pz - czoff) + gc.pos(i)] =
+                        (1 / 8.0f) * (sa[rc]) + (1 / 16.0f) * (sb[rc] + (sa[rn] + sa[rs])) +
+                        (1 / 32.0f) * ((sc[rc] + sb[rn]) + sb[rs]) + (1 / 64.0f) * (sc[rn] + sc[rs]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR - 2; r++) { rAm[r] = rAp[r]; rBm[r] = rBp[r]; }
+    }
+}
+
 // ------------------------------------------------------------------ sum of squares
 template <class real>
 __global__ void __launch_bounds__(256) sumsq_kernel(const real* __restrict__ x, size_t count, double* __restrict__ out) {
@@ -1290,6 +1479,27 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
     MGX_HIP(hipMemsetAsync(coarse_f + gc.PL * (size_t)(pzbeg - czoff), 0, gc.PL * (size_t)(pzend - pzbeg) * sizeof(real),
                            ctx->compute));
     if (cn[0] < 3 || cn[1] < 3) return MGX_OK;
+    if (ctx->rr_stream == 2) {  // rows shared through LDS, software-pipelined (residual_restrict3d_xs_pipe_kernel)
+        const int T = ctx->rr_tyw == 8 ? 8 : (ctx->rr_tyw == 2 ? 2 : 4);
+        const int gx = ceil_div(cn[0] - 2, 62), gy = ceil_div(cn[1] - 2, 2 * T);
+        int pzc = ctx->rr_pzchunk;
+        if (pzc <= 0) {
+            const int tiles = gx * gy, target = 2 * ctx->num_cus;
+            const int nchunks = max(1, (target + tiles / 2) / tiles);
+            pzc = max(4, ceil_div(pzend - pzbeg, nchunks));
+        }
+        dim3 g(gx, gy, ceil_div(pzend - pzbeg, pzc));
+#define MGX_RRP(M, W)                                                                                                    \
+    hipLaunchKernelGGL((residual_restrict3d_xs_pipe_kernel<real, M, W>), g, dim3(64, W, 1), 0, ctx->compute, v, f, n[0],  \
+                       n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzc, fzoff, czoff, pzbeg, pzend)
+        if (mode == MGX_RESIDUAL_REF_COMPAT) {
+            if (T == 8) MGX_RRP(0, 8); else if (T == 2) MGX_RRP(0, 2); else MGX_RRP(0, 4);
+        } else {
+            if (T == 8) MGX_RRP(1, 8); else if (T == 2) MGX_RRP(1, 2); else MGX_RRP(1, 4);
+        }
+#undef MGX_RRP
+        return MGX_OK;
+    }
     const int CRr = ctx->rr_cr == 1 ? 1 : 2, TYWr = ctx->rr_tyw == 8 ? 8 : (ctx->rr_tyw == 2 ? 2 : 4);
     const int gx = ceil_div(cn[0], 63), gy = ceil_div(cn[1] - 2, CRr * TYWr);
     int pzchunk = ctx->rr_pzchunk > 0 ? ctx->rr_pzchunk : 8;
@@ -1634,7 +1844,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "residual_restrict3d.tyw")) {
         ctx->rr_tyw = value;  // waves per block: 2, 4 or 8
     } else if (!strcmp(name, "residual_restrict3d.stream")) {
-        ctx->rr_stream = value ? 1 : 0;  // 1 = streaming shuffle kernel (x-split), 0 = LDS rolling-window kernel
+        ctx->rr_stream = value < 0 || value > 2 ? 1 : value;  // 0 = LDS rolling-window kernel, 1 = streaming shuffle kernel,
+                                                              // 2 = streaming with rows shared through LDS, pipelined (x-split)
     } else if (!strcmp(name, "residual_restrict3d.pzchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "residual_restrict3d.pzchunk must be >= 0 (0 = automatic)");
         ctx->rr_pzchunk = value;

@@ -98,10 +98,11 @@ def test_3d_smallest_grid_and_zero_sweeps(ctx, layout):
     assert_f64(ops.residual(ctx, v, f, n3, rg), O.residual3d(n3, rg, v, f, dtype=np.float64))
 
 
-@pytest.mark.parametrize("n3", [(9, 9, 9), (33, 17, 65), (129, 65, 17), (257, 33, 9)])
-@pytest.mark.parametrize("stream", [0, 1])
+@pytest.mark.parametrize("n3", [(9, 9, 9), (33, 17, 65), (129, 65, 17), (257, 33, 9), (513, 9, 17)])
+@pytest.mark.parametrize("stream", [0, 1, 2])
 def test_3d_xsplit_residual_restrict_variants(ctx, n3, stream):
-    """both x-split residual+restrict kernels (LDS rolling window / streaming shuffles) == oracle, all chunkings"""
+    """the x-split residual+restrict kernels (LDS rolling window / streaming shuffles / streaming with the shared rows
+    handed over through LDS) == oracle, all chunkings and workgroup heights"""
     rg = [-1, 1, 0, 2, 0.5, 3]
     rng = np.random.default_rng(sum(n3) + stream)
     ctx.set_param("residual_restrict3d.stream", stream)
@@ -112,11 +113,14 @@ def test_3d_xsplit_residual_restrict_variants(ctx, n3, stream):
             for mode in (P.REF_COMPAT, P.CORRECT):
                 want = O.restrict3d(n3, O.residual3d(n3, rg, v, f, mode, dtype=dtype), dtype=dtype)
                 for chunk in (0, 1, 3):
-                    ctx.set_param("residual_restrict3d.pzchunk", chunk)
-                    assert bits_equal(P.ops3dxs.residual_restrict(ctx, v, f, n3, rg, mode), want)
+                    for tyw in (4, 2, 8):
+                        ctx.set_param("residual_restrict3d.pzchunk", chunk)
+                        ctx.set_param("residual_restrict3d.tyw", tyw)
+                        assert bits_equal(P.ops3dxs.residual_restrict(ctx, v, f, n3, rg, mode), want), (dtype, mode, chunk, tyw)
     finally:
         ctx.set_param("residual_restrict3d.stream", 1)
         ctx.set_param("residual_restrict3d.pzchunk", 0)
+        ctx.set_param("residual_restrict3d.tyw", 4)
 
 
 @pytest.mark.parametrize("layout", ["natural", "xsplit"])
