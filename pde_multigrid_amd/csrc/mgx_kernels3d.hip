@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
 //   5. waits for what it issued in 1 (explicit s_waitcnt vmcnt(0)) and renames the register sets.
 // Loads and stores therefore have the whole step (LDS traffic, ~40 fp64 operations per point, the barrier) to
 // complete, and a wave has memory requests in flight all the time instead of only while it waits for them.
-template <class real, int WX, int WY, int R>
+template <class real, int WX, int WY, int R, bool FNT = false>
 __global__ void __launch_bounds__(64 * WX * WY)
     relax3d_xs_pipe_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                            int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
         cp[r] = pv[roff[r] - sxy + qr * H + j];
         cc[r] = pv[roff[r] + (1 - qr) * H + j];
         cu[r] = pv[roff[r] + sxy + qr * H + j];
-        fc[r] = pf[roff[r] + qr * H + j];
+        fc[r] = (FNT ? __builtin_nontemporal_load(&pf[roff[r] + qr * H + j]) : pf[roff[r] + qr * H + j]);
         xc[r] = xn[r] = 0;
         op[r] = 0;
     }
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
             for (int r = 0; r < R; r++) {
                 const int qn = q ^ 1 ^ (r & 1);  // row parity in plane z+1
                 cn[r] = pv[roff[r] + 2 * sxy + qn * H + j];
-                fn[r] = pf[roff[r] + sxy + qn * H + j];
+                fn[r] = (FNT ? __builtin_nontemporal_load(&pf[roff[r] + sxy + qn * H + j]) : pf[roff[r] + sxy + qn * H + j]);
             }
             MGX_LOAD_RIM(1, q ^ 1, xn, Nn, Sn);
             publish((z + 1) & 1, cu);
@@ -1263,7 +1263,11 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
                           real hz2, int colour, int zchunk) {
     const int M = (sx + 1) / 2;
     const int gx = ceil_div(M - 1, 64 * WX), gy = ceil_div(sy - 2, WY * R), gz = ceil_div(zend - zbeg, zchunk);
-    if (ctx->relax_lds >= 1000)
+    if (ctx->relax_lds >= 3000 && R == 2 && WX * WY == 16)  // + 2000: f is loaded non-temporally (it is read once per pass)
+        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, WX, WY, (R == 2 && WX * WY == 16 ? R : 2), true>),
+                           dim3((unsigned)gx * gy * gz), dim3(64, WX * WY, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zbeg,
+                           zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd == 1 ? 1 : 0);
+    else if (ctx->relax_lds >= 1000)
         hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, WX, WY, R>), dim3((unsigned)gx * gy * gz), dim3(64, WX * WY, 1), 0,
                            ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy,
                            ctx->relax_xcd == 1 ? 1 : 0);
@@ -1289,7 +1293,9 @@ static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, in
         // bytes per wave and wants 8 x as many, shorter runs); below 257^2 rows, or for runs of a few planes (the
         // edge planes of a z-slab), relax3d_xs_kernel is faster.
         if (M - 1 < 128 || sy - 2 < 64 || zend - zbeg < 8) return false;
-        code = 1282;
+        // f is read exactly once per pass: load it non-temporally when the pass is too large to stay in the 256 MiB
+        // Infinity Cache anyway (+1.5 % at 513^3 and 1025^3); a cache-resident level (257^3) is 5 % faster without
+        code = (size_t)sx * sy * (size_t)(zend - zbeg) * sizeof(real) > ((size_t)256 << 20) ? 3282 : 1282;
         if (zchunk <= 0) {
             const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, 16);
             const int target = ctx->num_cus * (sizeof(real) == 4 ? 8 : 1);

@@ -180,7 +180,8 @@ def test_3d_xsplit_relax_tuning_knobs_do_not_change_results(ctx, ty, rows, zchun
 
 
 @pytest.mark.parametrize("code", [424, 444, 442, 422, 244, 224, 144, 184, 282, 242, 428, 228, 824, 814, 414, 418,
-                                  1424, 1444, 1442, 1422, 1244, 1224, 1144, 1184, 1282, 1242, 1428, 1228, 1824, 1814, 1414, 1418])
+                                  1424, 1444, 1442, 1422, 1244, 1224, 1144, 1184, 1282, 1242, 1428, 1228, 1824, 1814, 1414, 1418,
+                                  3282, 3442])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_3d_xsplit_relax_lds_exchange_shapes(ctx, code, dtype):
     """relax3d_xs_lds_kernel (edge rows / edge lanes handed over through LDS) and relax3d_xs_pipe_kernel (code + 1000:
