@@ -80,6 +80,22 @@ def test_dist_vcycle_random_inputs_f32_and_correct_mode(nranks):
 
 
 @pytest.mark.timeout(200)
+@pytest.mark.parametrize("nranks,dtype", [(2, np.float64), (4, np.float64), (2, np.float32)])
+def test_dist_vcycle_wide_rows_pipelined_smoother_on_slabs(nranks, dtype):
+    """257 x 129 rows: the slabs' interior planes run the pipelined LDS-exchange smoother (automatic choice), their
+    edge planes the small-workgroup kernel; random data so that every ghost plane matters"""
+    n3 = [257, 129, 65]
+    rng = np.random.default_rng(7 + nranks)
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    v0 = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    f0 = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    got, info = run_ranks(nranks, n3, rg, dtype, 2, 2, 1, 8, v0=v0, f0=f0)
+    assert info[0][0] >= 1
+    want = O.cycle3d(n3, rg, mode=0, v1=2, v2=2, reps=1, v=v0, f=f0, dtype=dtype)
+    assert bits_equal(got, want)
+
+
+@pytest.mark.timeout(200)
 def test_dist_vcycle_8_ranks_129(known_answers):
     """8 slabs of 16 planes at 129^3 (the 8-GPU shape of the node), reference semantics in fp32"""
     got, info = run_ranks(8, [129] * 3, R3, np.float32, 2, 2, 1, 4)
