@@ -50,6 +50,7 @@ int mg_dist_num_levels(int sizeZ_finest, int nranks, int numGrids, int min_plane
 int mg_dist_num_levels_single(int sizeZ_finest, int numGrids, int min_planes);
 int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
 
+#define MG_MAX_LEVELS 32 /* (int)log2(size-1) of any int size */
 #define MG_DECLARE(R, real)                                                                              \
     /* ------------------------------------------------------------------ 3D ------ */                  \
     typedef struct mgGrid3D_##R {                                                                        \
@@ -74,6 +75,12 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         int layout; /* device layout of d_v/d_f/d_r/d_e: 0 = reference layout, 1 = x-split (mgx.h) */    \
         int smoother; /* 0 = red-black Gauss-Seidel (the reference), 1 = weighted Jacobi (addition) */   \
         real omega;   /* Jacobi weight, default 2/3 */                                                   \
+        int use_graph; /* 1: VCycle(gridID, v1, v2) is captured into a HIP graph on first use and     */ \
+                       /* replayed afterwards (re-captured when its arguments or the fields above     */ \
+                       /* change; context parameters are frozen at capture time).  Default 0.         */ \
+        int capturing;                                                                                   \
+        void* graph_exec[MG_MAX_LEVELS];                                                                 \
+        long long graph_key[MG_MAX_LEVELS];                                                              \
     } mgMultiGrid3D_##R;                                                                                 \
     int mgMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6],     \
                                    mgMultiGrid3D_##R** out);                                             \
@@ -166,6 +173,10 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         int fuse;                                                                                        \
         int smoother; /* 0 = red-black Gauss-Seidel (the reference), 1 = weighted Jacobi (addition) */   \
         real omega;                                                                                      \
+        int use_graph; /* as in mgMultiGrid3D: the 1025^2 cycle is launch-bound */                       \
+        int capturing;                                                                                   \
+        void* graph_exec[MG_MAX_LEVELS];                                                                 \
+        long long graph_key[MG_MAX_LEVELS];                                                              \
     } mgMultiGrid2D_##R;                                                                                 \
     int mgMultiGrid2D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXY[2], const real range[4],     \
                                    const real* A, int A_size, int alfa, mgMultiGrid2D_##R** out);        \

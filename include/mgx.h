@@ -96,6 +96,13 @@ int mgx_memcpy_d2d(mgx_ctx* ctx, void* dst, const void* src, size_t bytes);     
 int mgx_memset_zero(mgx_ctx* ctx, void* dst, size_t bytes);                      /* async    */
 
 /* ---- timing on the compute stream (HIP events) ------------------------------------ */
+/* HIP graphs for the launch-bound parts (2D cycles, coarse 3D levels): everything the calls between _begin and _end
+ * enqueue on the context's compute stream is captured instead of executed and instantiated as one executable graph;
+ * _launch replays it with a single launch.  The host layer's VCycle does this itself when `use_graph` is set. */
+int mgx_graph_begin(mgx_ctx* ctx);
+int mgx_graph_end(mgx_ctx* ctx, void** graph_exec);
+int mgx_graph_launch(mgx_ctx* ctx, void* graph_exec);
+int mgx_graph_destroy(mgx_ctx* ctx, void* graph_exec);
 int mgx_event_create(mgx_ctx* ctx, mgx_event** out);
 int mgx_event_destroy(mgx_ctx* ctx, mgx_event* ev);
 int mgx_event_record(mgx_ctx* ctx, mgx_event* ev);

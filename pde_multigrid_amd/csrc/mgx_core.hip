@@ -174,6 +174,37 @@ int mgx_memset_zero(mgx_ctx* ctx, void* dst, size_t bytes) {
     return MGX_OK;
 }
 
+int mgx_graph_begin(mgx_ctx* ctx) {
+    MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_HIP(hipStreamBeginCapture(ctx->compute, hipStreamCaptureModeThreadLocal));
+    return MGX_OK;
+}
+
+int mgx_graph_end(mgx_ctx* ctx, void** graph_exec) {
+    MGX_REQUIRE(ctx && graph_exec, MGX_ERR_INVALID, "NULL argument");
+    *graph_exec = nullptr;
+    hipGraph_t g = nullptr;
+    MGX_HIP(hipStreamEndCapture(ctx->compute, &g));
+    hipGraphExec_t e = nullptr;
+    hipError_t r = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (r != hipSuccess) return mgx::fail(MGX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(r));
+    *graph_exec = (void*)e;
+    return MGX_OK;
+}
+
+int mgx_graph_launch(mgx_ctx* ctx, void* graph_exec) {
+    MGX_REQUIRE(ctx && graph_exec, MGX_ERR_INVALID, "NULL argument");
+    MGX_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->compute));
+    return MGX_OK;
+}
+
+int mgx_graph_destroy(mgx_ctx* ctx, void* graph_exec) {
+    MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    if (graph_exec) MGX_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return MGX_OK;
+}
+
 int mgx_event_create(mgx_ctx* ctx, mgx_event** out) {
     MGX_REQUIRE(ctx && out, MGX_ERR_INVALID, "NULL argument");
     mgx_event* e = new mgx_event();

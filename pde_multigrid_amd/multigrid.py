@@ -339,7 +339,8 @@ def _grid3_struct(ct):
     class MultiGrid3D(C.Structure):
         _fields_ = [("grids3D", C.POINTER(C.POINTER(Grid3D))), ("numGrids", C.c_int), ("maxGrids", C.c_int),
                     ("ctx", C.c_void_p), ("residual_mode", C.c_int), ("fuse", C.c_int), ("layout", C.c_int),
-                    ("smoother", C.c_int), ("omega", ct)]
+                    ("smoother", C.c_int), ("omega", ct), ("use_graph", C.c_int), ("capturing", C.c_int),
+                    ("graph_exec", C.c_void_p * 32), ("graph_key", C.c_longlong * 32)]
 
     return Grid3D, MultiGrid3D
 
@@ -353,7 +354,8 @@ def _grid2_struct(ct):
     class MultiGrid2D(C.Structure):
         _fields_ = [("grids2D", C.POINTER(C.POINTER(Grid2D))), ("numGrids", C.c_int), ("maxGrids", C.c_int),
                     ("matrixA", ct * 4), ("sizeA", C.c_int), ("alfa", C.c_int), ("ctx", C.c_void_p), ("fuse", C.c_int),
-                    ("smoother", C.c_int), ("omega", ct)]
+                    ("smoother", C.c_int), ("omega", ct), ("use_graph", C.c_int), ("capturing", C.c_int),
+                    ("graph_exec", C.c_void_p * 32), ("graph_key", C.c_longlong * 32)]
 
     return Grid2D, MultiGrid2D
 
@@ -384,6 +386,15 @@ class _MGBase:
         if not 1 <= int(k) <= self._mg.contents.maxGrids:
             raise ValueError("numGrids must be in [1, %d]" % self._mg.contents.maxGrids)
         self._mg.contents.numGrids = int(k)
+
+    @property
+    def use_graph(self):
+        """2D / 3D: capture VCycle into a HIP graph on first use and replay it (mg_multigrid.h)"""
+        return bool(self._mg.contents.use_graph)
+
+    @use_graph.setter
+    def use_graph(self, on):
+        self._mg.contents.use_graph = 1 if on else 0
 
     @property
     def maxGrids(self):

@@ -417,6 +417,45 @@ def test_2d_baseline_config1_1025_f64(ctx):
     mg.close()
 
 
+def test_hip_graph_replay_of_cycles_2d_and_3d(ctx):
+    """use_graph: VCycle captured into a HIP graph on first use and replayed; re-captured when its arguments change;
+    FMG (one graph per starting level).  Bit-identical to the launch-by-launch path / the oracle."""
+    mg = P.MultiGrid2D(ctx, [1025] * 2, [0, 1, 0, 1], A2, 2, np.float64, nlevels=7)
+    mg.use_graph = True
+    for _ in range(3):
+        mg.VCycle(0, 2, 2)
+    mg.VCycle(0, 1, 3)  # other arguments: new capture
+    mg.VCycle(0, 2, 2)
+    ref = P.MultiGrid2D(ctx, [1025] * 2, [0, 1, 0, 1], A2, 2, np.float64, nlevels=7)
+    for _ in range(3):
+        ref.VCycle(0, 2, 2)
+    ref.VCycle(0, 1, 3)
+    ref.VCycle(0, 2, 2)
+    assert bits_equal(mg.download_v(0), ref.download_v(0))
+    mg.close()
+    ref.close()
+    mg = P.MultiGrid2D(ctx, [257] * 2, [0, 20, 0, 20], A2, 2, np.float64)
+    mg.use_graph = True
+    mg.FullMultiGridVCycle(0, 1, 50, 50)
+    assert_f64(mg.download_v(0), O.cycle2d([257] * 2, [0, 20, 0, 20], A2, 2, mode=1, v0=1, v1=50, v2=50, dtype=np.float64))
+    mg.close()
+    for layout in ("xsplit", "natural"):
+        mg = P.MultiGrid3D(ctx, [129] * 3, R3, np.float64, residual_mode=P.CORRECT, layout=layout)
+        mg.use_graph = True
+        mg.FullMultiGridVCycle(0, 2, 2, 2)
+        want = O.cycle3d([129] * 3, R3, mode=1, v0=2, v1=2, v2=2, residual_mode=P.CORRECT, dtype=np.float64)
+        assert_f64(mg.download_v(0), want)
+        mg.numGrids = 4  # public field changed: the key changes, new capture
+        mg.VCycle(0, 2, 1)
+        mg.close()
+    mg = P.MultiGrid3D(ctx, [65] * 3, R3, np.float32)
+    mg.use_graph = True
+    mg.VCycle(0, 2, 2)
+    mg.VCycle(0, 2, 2)
+    assert bits_equal(mg.download_v(0), O.cycle3d([65] * 3, R3, mode=0, v1=2, v2=2, reps=2, dtype=np.float32))
+    mg.close()
+
+
 def test_norm2_wave_reduction(ctx):
     rng = np.random.default_rng(0)
     for cnt in (1, 63, 64, 65, 1000003):
