@@ -352,6 +352,21 @@ def test_3d_full_size_513_sweep_and_properties(ctx):
     mg.close()
 
 
+@pytest.mark.timeout(600)
+def test_3d_bench_workload_513_vcycle_bit_exact(ctx):
+    """the workload of bench.py itself -- BASELINE.json configs[3]: 513 points per axis, fp64, native 9 levels, analytic
+    RHS, v = 0, one V(2,2) cycle with default parameters (pipelined smoother, fused operators, black-only correction)
+    -- against the oracle on every one of the 135 M points (about 15 s of single-threaded CPU)"""
+    n = 513
+    mg = P.MultiGrid3D(ctx, [n] * 3, R3, np.float64)
+    assert mg.numGrids == 9
+    mg.VCycle(0, 2, 2)
+    got = mg.download_v(0)
+    mg.close()
+    want = O.cycle3d([n] * 3, R3, mode=0, v1=2, v2=2, reps=1, dtype=np.float64)
+    assert bits_equal(got, want)
+
+
 # ------------------------------------------------------------------ 2D
 @pytest.mark.parametrize("n", [9, 17, 33])
 def test_2d_ops_f32_vs_reference_fixtures(ctx, n):
