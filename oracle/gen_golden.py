@@ -109,6 +109,7 @@ def known_answers():
         ("3d_n33_vcycle22", dict(n=33, mode=0, v1=2, v2=2)),
         ("3d_n65_vcycle22", dict(n=65, mode=0, v1=2, v2=2)),
         ("3d_n257_vcycle22_6lev", dict(n=257, mode=0, v1=2, v2=2, nlevels=6)),  # BASELINE config 3
+        ("3d_n513_vcycle22_9lev", dict(n=513, mode=0, v1=2, v2=2)),  # bench.py's size, in the reference's own fp32 (1 min)
         ("3d_n17_fmg_2_3000_3000", dict(n=17, mode=1, v0=2, v1=3000, v2=3000)),  # thesis parameters
         ("3d_n129_relax10", dict(n=129, mode=0, v1=10, v2=0, nlevels=1)),
         ("3d_n257_relax4", dict(n=257, mode=0, v1=4, v2=0, nlevels=1)),

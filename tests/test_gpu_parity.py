@@ -266,7 +266,7 @@ def test_3d_size_violations_return_status(ctx):
 
 # ------------------------------------------------------------------ 3D cycles
 @pytest.mark.parametrize("name", ["3d_n9_fmg122", "3d_n17_fmg122", "3d_n33_vcycle22", "3d_n65_vcycle22",
-                                  "3d_n129_relax10", "3d_n257_vcycle22_6lev", "3d_n257_relax4"])
+                                  "3d_n129_relax10", "3d_n257_vcycle22_6lev", "3d_n257_relax4", "3d_n513_vcycle22_9lev"])
 @pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("layout", ["natural", "xsplit"])
 def test_3d_reference_known_answers_f32(ctx, known_answers, name, fuse, layout):
