@@ -81,6 +81,10 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         int capturing;                                                                                   \
         void* graph_exec[MG_MAX_LEVELS];                                                                 \
         long long graph_key[MG_MAX_LEVELS];                                                              \
+        /* internal: 1 when the boundary entries of level l's d_f are known to be 0 (left so by the     */ \
+        /* previous cycle's residual+restrict); cleared by InitF / upload_f / Restrict / setToValue.    */ \
+        /* Those entries are never read by any operator; the flag only saves re-zeroing them.           */ \
+        unsigned char f_rim_zero[MG_MAX_LEVELS];                                                         \
     } mgMultiGrid3D_##R;                                                                                 \
     int mgMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6],     \
                                    mgMultiGrid3D_##R** out);                                             \

@@ -155,6 +155,11 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx3d_set_##SFX(mgx_ctx* ctx, real* grid, const int n[3], real value, int modify_boundaries);   \
     int mgx3d_residual_restrict_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[3],       \
                                       const real h[3], int mode, real* coarse_f, const int cn[3]);      \
+    /* _keep_rim: the boundary entries of coarse_f are NOT rewritten (the caller knows they are 0,      */ \
+    /* e.g. from the previous cycle); same interior results, one fill of the coarse array less.       */ \
+    int mgx3d_residual_restrict_keep_rim_##SFX(mgx_ctx* ctx, const real* v, const real* f,              \
+                                               const int n[3], const real h[3], int mode,               \
+                                               real* coarse_f, const int cn[3]);                        \
     int mgx3d_interpolate_correct_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,    \
                                         const int cn[3]);                                               \
     int mgx3d_init_f_##SFX(mgx_ctx* ctx, real* f, const int n[3], double c, const double* host_tx,      \
@@ -183,6 +188,9 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx3dxs_set_##SFX(mgx_ctx* ctx, real* grid, const int n[3], real value, int modify_boundaries); \
     int mgx3dxs_residual_restrict_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[3],     \
                                         const real h[3], int mode, real* coarse_f, const int cn[3]);    \
+    int mgx3dxs_residual_restrict_keep_rim_##SFX(mgx_ctx* ctx, const real* v, const real* f,            \
+                                                 const int n[3], const real h[3], int mode,             \
+                                                 real* coarse_f, const int cn[3]);                      \
     int mgx3dxs_interpolate_correct_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,  \
                                           const int cn[3]);                                             \
     int mgx3dxs_init_f_##SFX(mgx_ctx* ctx, real* f, const int n[3], double c, const double* host_tx,    \

@@ -1469,6 +1469,13 @@ int set3d(mgx_ctx* ctx, real* g, const int n[3], real value, int modify_boundari
     int st = check_n3(n, "set3d");
     if (st) return st;
     const int lo = modify_boundaries ? 0 : 1;
+    if (modify_boundaries && value == (real)0 && !std::signbit(value)) {
+        // the cycle's "coarse v := 0" (N3/MultiGrid3D.cpp:634): +0.0 is all-zero bits, the pad entries of the x-split
+        // layout are zero by invariant -> one fill of the whole array at memset speed
+        const size_t elems = Geo<L, real>(n[0], n[1]).PL * (size_t)n[2];  // natural layout: PL = n[0] * n[1]
+        MGX_HIP(hipMemsetAsync(g, 0, elems * sizeof(real), ctx->compute));
+        return MGX_OK;
+    }
     hipLaunchKernelGGL((set3d_kernel<real, L>), grd(n[0] - 2 * lo, n[1] - 2 * lo, n[2] - 2 * lo), blk(), 0, ctx->compute, g,
                        n[0], n[1], n[2], value, lo);
     MGX_LAUNCH_CHECK();
@@ -1480,10 +1487,13 @@ int set3d(mgx_ctx* ctx, real* g, const int n[3], real value, int modify_boundari
 template <class real>
 static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real* f, const int n[3], real hx2, real hy2,
                                          real hz2, int mode, real* coarse_f, const int cn[3], int fzoff, int czoff, int pzbeg,
-                                         int pzend) {
+                                         int pzend, bool rim_is_zero = false) {
     const Geo<XSplit, real> gc(cn[0], cn[1]);
-    MGX_HIP(hipMemsetAsync(coarse_f + gc.PL * (size_t)(pzbeg - czoff), 0, gc.PL * (size_t)(pzend - pzbeg) * sizeof(real),
-                           ctx->compute));
+    // the kernels write every interior coarse point of the planes and nothing else: boundary points and pad entries
+    // are zeroed here unless the caller vouches that they already are (they stay zero from one cycle to the next)
+    if (!rim_is_zero)
+        MGX_HIP(hipMemsetAsync(coarse_f + gc.PL * (size_t)(pzbeg - czoff), 0, gc.PL * (size_t)(pzend - pzbeg) * sizeof(real),
+                               ctx->compute));
     if (cn[0] < 3 || cn[1] < 3) return MGX_OK;
     if (ctx->rr_stream == 2) {  // rows shared through LDS, software-pipelined (residual_restrict3d_xs_pipe_kernel)
         const int T = ctx->rr_tyw == 8 ? 8 : (ctx->rr_tyw == 2 ? 2 : 4);
@@ -1532,7 +1542,7 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
 
 template <class real, class L>
 int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[3], const real h[3], int mode,
-                        real* coarse_f, const int cn[3]) {
+                        real* coarse_f, const int cn[3], bool rim_is_zero = false) {
     MGX_REQUIRE(ctx && v && f && h && coarse_f, MGX_ERR_INVALID, "residual_restrict3d: NULL argument");
     int st = check_n3(n, "residual_restrict3d");
     if (st) return st;
@@ -1542,7 +1552,7 @@ int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[
                 "residual_restrict3d: bad mode %d", mode);
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
     if (L::xsplit && ctx->rr_stream) {
-        st = residual_restrict3d_xs_launch<real>(ctx, v, f, n, hx2, hy2, hz2, mode, coarse_f, cn, 0, 0, 0, cn[2]);
+        st = residual_restrict3d_xs_launch<real>(ctx, v, f, n, hx2, hy2, hz2, mode, coarse_f, cn, 0, 0, 0, cn[2], rim_is_zero);
         if (st) return st;
         MGX_LAUNCH_CHECK();
         return MGX_OK;
@@ -1758,6 +1768,10 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
     int PFX##residual_restrict_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[3], const real h[3], \
                                      int mode, real* coarse_f, const int cn[3]) {                                \
         return mgx::residual_restrict3d<real, L>(ctx, v, f, n, h, mode, coarse_f, cn);                           \
+    }                                                                                                            \
+    int PFX##residual_restrict_keep_rim_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[3],        \
+                                              const real h[3], int mode, real* coarse_f, const int cn[3]) {      \
+        return mgx::residual_restrict3d<real, L>(ctx, v, f, n, h, mode, coarse_f, cn, true);                     \
     }                                                                                                            \
     int PFX##interpolate_correct_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,              \
                                        const int cn[3]) {                                                        \

@@ -340,7 +340,7 @@ def _grid3_struct(ct):
         _fields_ = [("grids3D", C.POINTER(C.POINTER(Grid3D))), ("numGrids", C.c_int), ("maxGrids", C.c_int),
                     ("ctx", C.c_void_p), ("residual_mode", C.c_int), ("fuse", C.c_int), ("layout", C.c_int),
                     ("smoother", C.c_int), ("omega", ct), ("use_graph", C.c_int), ("capturing", C.c_int),
-                    ("graph_exec", C.c_void_p * 32), ("graph_key", C.c_longlong * 32)]
+                    ("graph_exec", C.c_void_p * 32), ("graph_key", C.c_longlong * 32), ("f_rim_zero", C.c_ubyte * 32)]
 
     return Grid3D, MultiGrid3D
 

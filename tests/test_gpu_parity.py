@@ -432,6 +432,40 @@ def test_2d_baseline_config1_1025_f64(ctx):
     mg.close()
 
 
+@pytest.mark.parametrize("layout", ["xsplit", "natural"])
+def test_3d_coarse_rhs_rim_is_zero_after_every_cycle(ctx, layout):
+    """the cycle re-zeroes the boundary entries of a coarse level's f only when something wrote there since the last
+    residual+restrict (flag f_rim_zero); whatever the history, after a cycle they are 0 like in the reference"""
+    n = 33
+    mg = P.MultiGrid3D(ctx, [n] * 3, [-1, 1, 0, 2, 0.5, 3], np.float64, layout=layout)
+
+    def rim_is_zero(level):
+        f = mg.download_f(level)
+        inner = f[1:-1, 1:-1, 1:-1].copy()
+        f[1:-1, 1:-1, 1:-1] = 0
+        return not f.any() and inner.any()
+
+    mg.VCycle(0, 2, 2)
+    assert rim_is_zero(1) and rim_is_zero(2)
+    mg.VCycle(0, 2, 2)  # second cycle: the keep-rim form of residual+restrict
+    assert rim_is_zero(1) and rim_is_zero(2)
+    junk = np.random.default_rng(0).uniform(1, 2, (17, 17, 17))
+    mg.upload_f(1, junk)  # non-zero boundary written from outside
+    mg.VCycle(0, 2, 2)
+    assert rim_is_zero(1)
+    mg.FullMultiGridVCycle(0, 1, 2, 2)  # FMG's Restrict(f) injects the fine boundary, the cycles zero it again
+    assert rim_is_zero(1) and rim_is_zero(2)
+    want = None
+    mg.close()
+    # and the values of v are those of the oracle after the same sequence of calls on fresh hierarchies (fused paths)
+    mg = P.MultiGrid3D(ctx, [n] * 3, R3, np.float64, layout=layout)
+    for _ in range(3):
+        mg.VCycle(0, 2, 2)
+    want = O.cycle3d([n] * 3, R3, mode=0, v1=2, v2=2, reps=3, dtype=np.float64)
+    assert bits_equal(mg.download_v(0), want)
+    mg.close()
+
+
 def test_hip_graph_replay_of_cycles_2d_and_3d(ctx):
     """use_graph: VCycle captured into a HIP graph on first use and replayed; re-captured when its arguments change;
     FMG (one graph per starting level).  Bit-identical to the launch-by-launch path / the oracle."""
