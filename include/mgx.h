@@ -228,6 +228,12 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                              const real h[2], const real a[2], const real A[4], int alfa);              \
     int mgx2d_restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[2], real* coarse,             \
                              const int cn[2]);                                                          \
+    /* fused forms of the cycle (N2/MultiGrid2D.cpp:320-323, 333-335): no residual / error array */    \
+    int mgx2d_residual_restrict_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[2],       \
+                                      const real h[2], const real a[2], const real A[4], int alfa,      \
+                                      real* coarse_f, const int cn[2]);                                 \
+    int mgx2d_interpolate_correct_##SFX(mgx_ctx* ctx, real* v, const int n[2], const real* coarse_v,    \
+                                        const int cn[2]);                                               \
     int mgx2d_interpolate_##SFX(mgx_ctx* ctx, real* fine, const int fn[2], const real* coarse,          \
                                 const int cn[2]);                                                       \
     int mgx2d_apply_correction_##SFX(mgx_ctx* ctx, real* fine, const int fn[2], const real* err,        \

@@ -81,6 +81,37 @@ __global__ void __launch_bounds__(256) restrict2d_kernel(const real* __restrict_
     coarse[ci] = (1 / 16.0f) * (NO + NE + SO + SE + 2 * (O + E + N + S) + 4 * C);  // :123
 }
 
+// residual + restrict in one launch (VCycle, N2/MultiGrid2D.cpp:320-323): one thread per coarse point evaluates the
+// nine fine residuals it needs (the level is cache resident: recomputing costs less than a second launch and the
+// residual array) with the expression of :403 and combines them with the association of :123.
+template <class real>
+__global__ void __launch_bounds__(256) residual_restrict2d_kernel(const real* __restrict__ v, const real* __restrict__ f, int fx,
+                                                                  int fy, Lyap2<real> k, real* __restrict__ coarse, int cx,
+                                                                  int cy) {
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    const int py = blockIdx.y * blockDim.y + threadIdx.y;
+    if (px >= cx || py >= cy) return;
+    const size_t ci = px + (size_t)py * cx;
+    if (px == 0 || px == cx - 1 || py == 0 || py == cy - 1) {
+        coarse[ci] = (real)0;  // injection of a boundary residual, which is 0 (:389-392 then :95-101)
+        return;
+    }
+    auto res = [&](int x, int y) -> real {
+        if (x == 0 || x == fx - 1 || y == 0 || y == fy - 1) return (real)0;
+        const size_t i = x + (size_t)y * fx;
+        const real xj = k.ax + x * k.hx;
+        const real yi = k.ay + y * k.hy;
+        const real K1 = k.A0 * xj + k.A1 * yi;
+        const real K2 = k.A2 * xj + k.A3 * yi;
+        return f[i] - (k.hy * K1 * v[i + 1] + k.hx * K2 * v[i + fx] - v[i] * (k.hy * K1 + k.hx * K2 - k.alfa * k.hx * k.hy)) /
+                          (k.hx * k.hy);
+    };
+    const int x = 2 * px, y = 2 * py;
+    const real C = res(x, y), N = res(x, y - 1), S = res(x, y + 1), E = res(x + 1, y), O = res(x - 1, y);
+    const real NE = res(x + 1, y - 1), NO = res(x - 1, y - 1), SE = res(x + 1, y + 1), SO = res(x - 1, y + 1);
+    coarse[ci] = (1 / 16.0f) * (NO + NE + SO + SE + 2 * (O + E + N + S) + 4 * C);  // :123
+}
+
 template <class real, bool ADD>
 __global__ void __launch_bounds__(256) interpolate2d_kernel(real* __restrict__ fine, int fx, int fy,
                                                             const real* __restrict__ coarse, int cx) {
@@ -302,6 +333,20 @@ int interpolate2d(mgx_ctx* ctx, real* fine, const int fn[2], const real* coarse,
 }
 
 template <class real>
+int residual_restrict2d(mgx_ctx* ctx, const real* v, const real* f, const int n[2], const real h[2], const real a[2],
+                        const real A[4], int alfa, real* coarse_f, const int cn[2]) {
+    MGX_REQUIRE(ctx && v && f && h && a && A && coarse_f, MGX_ERR_INVALID, "residual_restrict2d: NULL argument");
+    int st = check_n2(n, "residual_restrict2d");
+    if (st) return st;
+    st = check_coarse2(n, cn, "residual_restrict2d");
+    if (st) return st;
+    hipLaunchKernelGGL((residual_restrict2d_kernel<real>), grd2(cn[0], cn[1]), blk2(), 0, ctx->compute, v, f, n[0], n[1],
+                       lyap<real>(h, a, A, alfa), coarse_f, cn[0], cn[1]);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+template <class real>
 int correct2d(mgx_ctx* ctx, real* fine, const int fn[2], const real* err, const int en[2]) {
     MGX_REQUIRE(ctx && fine && err && en, MGX_ERR_INVALID, "apply_correction2d: NULL argument");
     int st = check_n2(fn, "apply_correction2d");
@@ -320,6 +365,10 @@ int set2d(mgx_ctx* ctx, real* g, const int n[2], real value, int modify_boundari
     int st = check_n2(n, "set2d");
     if (st) return st;
     const int lo = modify_boundaries ? 0 : 1;
+    if (modify_boundaries && value == (real)0 && !std::signbit(value)) {  // the cycle's "coarse v := 0" (:326)
+        MGX_HIP(hipMemsetAsync(g, 0, (size_t)n[0] * n[1] * sizeof(real), ctx->compute));
+        return MGX_OK;
+    }
     hipLaunchKernelGGL((set2d_kernel<real>), grd2(n[0] - 2 * lo, n[1] - 2 * lo), blk2(), 0, ctx->compute, g, n[0], n[1],
                        value, lo);
     MGX_LAUNCH_CHECK();
@@ -381,6 +430,14 @@ int mean_abs_error2d(mgx_ctx* ctx, const real* v, const int n[2], const real h[2
     int mgx2d_restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[2], real* coarse, const int cn[2]) {    \
         return mgx::restrict2d<real>(ctx, fine, fn, coarse, cn);                                                 \
     }                                                                                                            \
+    int mgx2d_residual_restrict_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[2], const real h[2], \
+                                      const real a[2], const real A[4], int alfa, real* coarse_f, const int cn[2]) { \
+        return mgx::residual_restrict2d<real>(ctx, v, f, n, h, a, A, alfa, coarse_f, cn);                         \
+    }                                                                                                             \
+    int mgx2d_interpolate_correct_##SFX(mgx_ctx* ctx, real* v, const int n[2], const real* coarse_v,              \
+                                        const int cn[2]) {                                                        \
+        return mgx::interpolate2d<real, true>(ctx, v, n, coarse_v, cn);                                           \
+    }                                                                                                             \
     int mgx2d_interpolate_##SFX(mgx_ctx* ctx, real* fine, const int fn[2], const real* coarse, const int cn[2]) { \
         return mgx::interpolate2d<real, false>(ctx, fine, fn, coarse, cn);                                       \
     }                                                                                                            \

@@ -323,6 +323,22 @@ class _Ops2D(_Ops):
                          dtype)
 
 
+    def residual_restrict(self, ctx, v, f, n, rng, A, alfa, dtype=None):
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("residual_restrict", dtype)
+        h, a, AA = self._geom(n, rng, A, dtype, ct)
+        cn = coarse_size(n)
+        c = np.zeros(_shape(cn), dtype)
+        return self._run(ctx, [v, f, c], lambda x, y, z: fn(ctx._h, x, y, _ip(n), h, a, AA, C.c_int(alfa), z, _ip(cn)), 2,
+                         _shape(cn), dtype)
+
+    def interpolate_correct(self, ctx, v, n, coarse, dtype=None):
+        dtype = dtype or v.dtype
+        fn, _ = self._fn("interpolate_correct", dtype)
+        cn = coarse_size(n)
+        return self._run(ctx, [v, coarse], lambda x, c: fn(ctx._h, x, _ip(n), c, _ip(cn)), 0, _shape(n), dtype)
+
+
 ops3d = _Ops3D()
 ops3dxs = _Ops3D(xsplit=True)
 ops2d = _Ops2D()
@@ -507,7 +523,7 @@ class MultiGrid2D(_MGBase):
     """MultiGrid2D(finestGridSizeXY, range, A, A_size, alfa) (N2/MultiGrid2D.h:6-37) on one MI355X."""
     _prefix = "mgMultiGrid2D"
 
-    def __init__(self, ctx, finestGridSizeXY, rng, A, alfa, dtype=np.float64, nlevels=0):
+    def __init__(self, ctx, finestGridSizeXY, rng, A, alfa, dtype=np.float64, nlevels=0, fuse=True):
         self.ctx = ctx
         self.dtype = np.dtype(dtype)
         self._sfx, self._ct = _ct(dtype)
@@ -516,6 +532,7 @@ class MultiGrid2D(_MGBase):
         fn = getattr(lib, "mgMultiGrid2D_%s_create" % self._sfx)
         check(fn(ctx._h, _ip(finestGridSizeXY), _rp(rng, self._ct), _rp(A, self._ct), C.c_int(2), C.c_int(alfa),
                  C.byref(self._mg)))
+        self._mg.contents.fuse = int(bool(fuse))
         if nlevels:
             self.numGrids = nlevels
 

@@ -420,6 +420,29 @@ def test_2d_reference_known_answers_f32(ctx, known_answers, name):
     mg.close()
 
 
+@pytest.mark.parametrize("n2", [(9, 9), (33, 17), (129, 65), (17, 257)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_2d_fused_operators_vs_oracle(ctx, n2, dtype):
+    """mgx2d_residual_restrict == Restrict(CalculateResidual), mgx2d_interpolate_correct == ApplyCorrection(Interpolate)"""
+    rng = np.random.default_rng(sum(n2))
+    rg = [-1, 2, 0.5, 3]
+    cn = P.coarse_size(n2)
+    v = rng.uniform(-1, 1, O.shape(n2)).astype(dtype)
+    f = rng.uniform(-1, 1, O.shape(n2)).astype(dtype)
+    c = rng.uniform(-1, 1, O.shape(cn)).astype(dtype)
+    want = O.restrict2d(n2, O.residual2d(n2, rg, A2, 2, v, f, dtype=dtype), dtype=dtype)
+    assert bits_equal(P.ops2d.residual_restrict(ctx, v, f, n2, rg, A2, 2), want)
+    want = O.correct2d(n2, v, O.interpolate2d(n2, np.zeros(O.shape(n2), dtype), c, dtype=dtype), dtype=dtype)
+    assert bits_equal(P.ops2d.interpolate_correct(ctx, v, n2, c), want)
+
+
+def test_2d_unfused_cycle_path_still_matches(ctx):
+    mg = P.MultiGrid2D(ctx, [129] * 2, [0, 1, 0, 1], A2, 2, np.float64, fuse=False)
+    mg.FullMultiGridVCycle(0, 1, 2, 2)
+    assert_f64(mg.download_v(0), O.cycle2d([129] * 2, [0, 1, 0, 1], A2, 2, mode=1, v0=1, v1=2, v2=2, dtype=np.float64))
+    mg.close()
+
+
 def test_2d_baseline_config1_1025_f64(ctx):
     """BASELINE.json configs[1]: 2D Lyapunov 1024x1024 (1025 points/axis), 7-level V-cycle, fp64."""
     mg = P.MultiGrid2D(ctx, [1025] * 2, [0, 1, 0, 1], A2, 2, np.float64, nlevels=7)
