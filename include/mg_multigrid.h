@@ -142,6 +142,7 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         int rank, nranks;                                                                                \
         int residual_mode;                                                                               \
         real* d_share;             /* staging for the agglomeration all-gather */                        \
+        real* d_bplane;            /* FMG: staging for the top boundary plane of the replicated f */     \
     } mgDistMultiGrid3D_##R;                                                                             \
     int mgDistMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6], \
                                        int min_planes, mgDistMultiGrid3D_##R** out);                     \
@@ -149,6 +150,9 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
     int mgDistMultiGrid3D_##R##_InitF(mgDistMultiGrid3D_##R* mg, int gridID);                            \
     int mgDistMultiGrid3D_##R##_Relax(mgDistMultiGrid3D_##R* mg, int gridID, int ncycles);               \
     int mgDistMultiGrid3D_##R##_VCycle(mgDistMultiGrid3D_##R* mg, int gridID, int v1, int v2);           \
+    /* FullMultiGridVCycle (N3/MultiGrid3D.cpp:569-585) on slabs                                        */ \
+    int mgDistMultiGrid3D_##R##_FullMultiGridVCycle(mgDistMultiGrid3D_##R* mg, int gridID, int v0,       \
+                                                    int v1, int v2);                                     \
     int mgDistMultiGrid3D_##R##_zero_v(mgDistMultiGrid3D_##R* mg, int gridID);                           \
     int mgDistMultiGrid3D_##R##_upload_v(mgDistMultiGrid3D_##R* mg, int gridID, const real* host_full);  \
     int mgDistMultiGrid3D_##R##_upload_f(mgDistMultiGrid3D_##R* mg, int gridID, const real* host_full);  \

@@ -211,6 +211,16 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                                              const int n[3], int fzoff, const real h[3], int mode,      \
                                              real* coarse_f, const int cn[3], int czoff, int pzbeg,     \
                                              int pzend);                                                \
+    /* FMG on slabs: Restrict (coarse planes [pzbeg, pzend); boundary points by injection) and plain  */ \
+    /* Interpolate (fine planes 2pz, 2pz+1 of every listed pz, interior points, z = 0 skipped).       */ \
+    /* setToValue(.., false) on the LOCAL planes [zbeg, zend) of a slab: their (x, y)-interior points  */ \
+    int mgx3dxs_set_interior_slab_##SFX(mgx_ctx* ctx, real* grid, int sx, int sy, int zbeg, int zend,   \
+                                        real value);                                                    \
+    int mgx3dxs_restrict_slab_##SFX(mgx_ctx* ctx, const real* fine, const int fn[3], int fzoff,         \
+                                    real* coarse, const int cn[3], int czoff, int pzbeg, int pzend);    \
+    int mgx3dxs_interpolate_slab_##SFX(mgx_ctx* ctx, real* fine, const int fn[3], int fzoff,            \
+                                       const real* coarse, const int cn[3], int czoff, int pzbeg,       \
+                                       int pzend);                                                      \
     int mgx3dxs_interpolate_correct_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff,        \
                                                const real* coarse_v, const int cn[3], int czoff,        \
                                                int pzbeg, int pzend);                                   \

@@ -651,15 +651,18 @@ __global__ void __launch_bounds__(256) residual3d_kernel(const real* __restrict_
 // ------------------------------------------------------------------ restrict
 template <class real, class L>
 __global__ void __launch_bounds__(256) restrict3d_kernel(const real* __restrict__ fine, int fx, int fy,
-                                                         real* __restrict__ coarse, int cx, int cy, int cz) {
+                                                         real* __restrict__ coarse, int cx, int cy, int cz, int fzoff,
+                                                         int czoff, int pzbeg) {
+    // z-slab form: cz = GLOBAL coarse planes; `fine` / `coarse` start at global planes fzoff / czoff; this launch covers
+    // the global coarse planes pzbeg + blockIdx.z (whole grid: all three are 0)
     const int px = blockIdx.x * blockDim.x + threadIdx.x;
     const int py = blockIdx.y * blockDim.y + threadIdx.y;
-    const int pz = blockIdx.z;
+    const int pz = pzbeg + blockIdx.z;
     if (px >= cx || py >= cy) return;
     const Geo<L, real> gf(fx, fy), gc(cx, cy);
     const int FH = gf.H;
-    const size_t ci = gc.pos(px) + gc.row(py, pz);
-    const real* c = fine + gf.row(2 * py, 2 * pz);  // row base of the fine centre
+    const size_t ci = gc.pos(px) + gc.row(py, pz - czoff);
+    const real* c = fine + gf.row(2 * py, 2 * pz - fzoff);  // row base of the fine centre
     const int gx = 2 * px;
     if (px == 0 || px == cx - 1 || py == 0 || py == cy - 1 || pz == 0 || pz == cz - 1) {
         coarse[ci] = c[L::pos(gx, FH)];  // injection, N3/MultiGrid3D.cpp:113-119
@@ -1428,7 +1431,25 @@ int restrict3d(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse, co
     st = check_coarse3(fn, cn, "restrict3d");
     if (st) return st;
     hipLaunchKernelGGL((restrict3d_kernel<real, L>), grd(cn[0], cn[1], cn[2]), blk(), 0, ctx->compute, fine, fn[0], fn[1],
-                       coarse, cn[0], cn[1], cn[2]);
+                       coarse, cn[0], cn[1], cn[2], 0, 0, 0);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+// Restrict on a z-slab: the global coarse planes [pzbeg, pzend); fine planes 2pz-1 .. 2pz+1 must be present in `fine`
+template <class real>
+int restrict3d_slab(mgx_ctx* ctx, const real* fine, const int fn[3], int fzoff, real* coarse, const int cn[3], int czoff,
+                    int pzbeg, int pzend) {
+    MGX_REQUIRE(ctx && fine && coarse, MGX_ERR_INVALID, "restrict_slab: NULL argument");
+    int st = check_n3(fn, "restrict_slab");
+    if (st) return st;
+    st = check_coarse3(fn, cn, "restrict_slab");
+    if (st) return st;
+    MGX_REQUIRE(pzbeg >= 0 && pzend <= cn[2] && pzbeg <= pzend && fzoff >= 0 && czoff >= 0 && czoff <= pzbeg, MGX_ERR_INVALID,
+                "restrict_slab: bad plane range");
+    if (pzbeg == pzend) return MGX_OK;
+    hipLaunchKernelGGL((restrict3d_kernel<real, XSplit>), grd(cn[0], cn[1], pzend - pzbeg), blk(), 0, ctx->compute, fine, fn[0],
+                       fn[1], coarse, cn[0], cn[1], cn[2], fzoff, czoff, pzbeg);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -1478,6 +1499,20 @@ int set3d(mgx_ctx* ctx, real* g, const int n[3], real value, int modify_boundari
     }
     hipLaunchKernelGGL((set3d_kernel<real, L>), grd(n[0] - 2 * lo, n[1] - 2 * lo, n[2] - 2 * lo), blk(), 0, ctx->compute, g,
                        n[0], n[1], n[2], value, lo);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+// setToValue(grid, value, false) on the local planes [zbeg, zend) of an x-split slab: their (x, y)-interior points
+template <class real>
+int set3d_slab(mgx_ctx* ctx, real* g, int sx, int sy, int zbeg, int zend, real value) {
+    MGX_REQUIRE(ctx && g, MGX_ERR_INVALID, "set_slab: NULL argument");
+    MGX_REQUIRE(valid_size(sx) && valid_size(sy) && zbeg >= 0 && zend >= zbeg, MGX_ERR_SIZE, "set_slab: bad sizes");
+    if (zend == zbeg) return MGX_OK;
+    // set3d_kernel with lo = 1 writes the planes 1 .. sz-2 of the array it is given: hand it the planes zbeg-1 .. zend
+    const Geo<XSplit, real> ge(sx, sy);
+    hipLaunchKernelGGL((set3d_kernel<real, XSplit>), grd(sx - 2, sy - 2, zend - zbeg), blk(), 0, ctx->compute,
+                       g + ge.PL * (size_t)zbeg - ge.PL, sx, sy, zend - zbeg + 2, value, 1);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -1655,7 +1690,7 @@ int residual_restrict3d_slab(mgx_ctx* ctx, const real* v, const real* f, const i
 
 template <class real>
 int interpolate_correct3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff, const real* coarse_v, const int cn[3],
-                               int czoff, int pzbeg, int pzend, int colour) {
+                               int czoff, int pzbeg, int pzend, int colour, bool add = true) {
     MGX_REQUIRE(ctx && v && coarse_v, MGX_ERR_INVALID, "interpolate_correct_slab: NULL argument");
     int st = check_n3(n, "interpolate_correct_slab");
     if (st) return st;
@@ -1666,6 +1701,12 @@ int interpolate_correct3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff,
     MGX_REQUIRE(colour >= -1 && colour <= 1, MGX_ERR_INVALID, "interpolate_correct_slab: colour %d not in {-1, 0, 1}", colour);
     if (pzbeg == pzend) return MGX_OK;
     const dim3 g = grd((n[0] + 1) / 2 - 1, cn[1] - 1, pzend - pzbeg);
+    if (!add) {  // plain Interpolate (FMG, N3/MultiGrid3D.cpp:577): all interior points of the fine planes
+        hipLaunchKernelGGL((interpolate3d_xs_kernel<real, false, -1>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
+                           cn[0], cn[1], czoff, pzbeg);
+        MGX_LAUNCH_CHECK();
+        return MGX_OK;
+    }
     if (colour < 0)
         hipLaunchKernelGGL((interpolate3d_xs_kernel<real, true, -1>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
                            cn[0], cn[1], czoff, pzbeg);
@@ -1809,6 +1850,19 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
                                                const real* coarse_v, const int cn[3], int czoff, int pzbeg,      \
                                                int pzend) {                                                      \
         return mgx::interpolate_correct3d_slab<real>(ctx, v, n, fzoff, coarse_v, cn, czoff, pzbeg, pzend, -1);   \
+    }                                                                                                            \
+    int mgx3dxs_set_interior_slab_##SFX(mgx_ctx* ctx, real* grid, int sx, int sy, int zbeg, int zend,            \
+                                        real value) {                                                            \
+        return mgx::set3d_slab<real>(ctx, grid, sx, sy, zbeg, zend, value);                                      \
+    }                                                                                                            \
+    int mgx3dxs_restrict_slab_##SFX(mgx_ctx* ctx, const real* fine, const int fn[3], int fzoff, real* coarse,     \
+                                    const int cn[3], int czoff, int pzbeg, int pzend) {                          \
+        return mgx::restrict3d_slab<real>(ctx, fine, fn, fzoff, coarse, cn, czoff, pzbeg, pzend);                \
+    }                                                                                                            \
+    int mgx3dxs_interpolate_slab_##SFX(mgx_ctx* ctx, real* fine, const int fn[3], int fzoff, const real* coarse, \
+                                       const int cn[3], int czoff, int pzbeg, int pzend) {                       \
+        return mgx::interpolate_correct3d_slab<real>(ctx, fine, fn, fzoff, coarse, cn, czoff, pzbeg, pzend, -1,  \
+                                                     false);                                                     \
     }                                                                                                            \
     int mgx3dxs_interpolate_correct_colour_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff,          \
                                                       const real* coarse_v, const int cn[3], int czoff,          \

@@ -677,7 +677,7 @@ def _dist_struct(ct):
     class DistMultiGrid3D(C.Structure):
         _fields_ = [("slabs", C.POINTER(C.POINTER(Slab3D))), ("numDist", C.c_int), ("numGrids", C.c_int), ("maxGrids", C.c_int),
                     ("tail", C.c_void_p), ("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
-                    ("residual_mode", C.c_int), ("d_share", C.c_void_p)]
+                    ("residual_mode", C.c_int), ("d_share", C.c_void_p), ("d_bplane", C.c_void_p)]
 
     return Slab3D, DistMultiGrid3D
 
@@ -734,9 +734,6 @@ class DistMultiGrid3D(_MGBase):
                                                                       C.c_int(g.sizeXYZ[0]), C.c_int(g.sizeXYZ[1]), h,
                                                                       C.c_int(colour), C.c_int(p.ubeg - p.zoff),
                                                                       C.c_int(p.uend - p.zoff), C.c_int(p.zoff)))
-
-    def FullMultiGridVCycle(self, *a):
-        raise NotImplementedError("the slab-decomposed path implements VCycle (the measured unit); FMG runs on one GPU")
 
     def upload_v(self, gridID, full):
         full = np.ascontiguousarray(full, self.dtype)

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 R3 = [0, 1, 0, 1, 0, 1]
 
 
-def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COMPAT, v0=None, f0=None, nlevels=0):
+def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COMPAT, v0=None, f0=None, nlevels=0, fmg=0):
     ctxs = [P.Context(0) for _ in range(nranks)]
     group = P.LocalGroup(nranks)
     for r, c in enumerate(ctxs):
@@ -33,6 +33,8 @@ def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COM
                 mg.upload_f(0, f0)
             if v0 is not None:
                 mg.upload_v(0, v0)
+            if fmg:
+                mg.FullMultiGridVCycle(0, fmg, v1, v2)
             for _ in range(cycles):
                 mg.VCycle(0, v1, v2)
             mg.download_v_into(0, full)
@@ -92,6 +94,30 @@ def test_dist_vcycle_wide_rows_pipelined_smoother_on_slabs(nranks, dtype):
     got, info = run_ranks(nranks, n3, rg, dtype, 2, 2, 1, 8, v0=v0, f0=f0)
     assert info[0][0] >= 1
     want = O.cycle3d(n3, rg, mode=0, v1=2, v2=2, reps=1, v=v0, f=f0, dtype=dtype)
+    assert bits_equal(got, want)
+
+
+@pytest.mark.timeout(200)
+@pytest.mark.parametrize("nranks", [1, 2, 4])
+@pytest.mark.parametrize("n,min_planes", [(33, 2), (65, 4), (65, 8)])
+def test_dist_fmg_matches_oracle(nranks, n, min_planes):
+    """FullMultiGridVCycle on slabs (Restrict of f with the ghost below, all-gather into the replicated tail incl. its top
+    boundary plane, plain Interpolate on the way up) == oracle, reference and corrected residual"""
+    for mode in (P.REF_COMPAT, P.CORRECT):
+        got, info = run_ranks(nranks, [n] * 3, R3, np.float64, 2, 2, 0, min_planes, mode=mode, fmg=1)
+        want = O.cycle3d([n] * 3, R3, mode=1, v0=1, v1=2, v2=2, residual_mode=mode, dtype=np.float64)
+        assert not np.isnan(got).any()
+        assert bits_equal(got, want), (mode, info)
+
+
+@pytest.mark.timeout(200)
+def test_dist_fmg_random_rhs_f32_then_vcycle():
+    n3 = [65, 33, 65]
+    rng = np.random.default_rng(11)
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    f0 = rng.uniform(-1, 1, O.shape(n3)).astype(np.float32)   # non-zero on the boundary: exercises the injected planes
+    got, _ = run_ranks(4, n3, rg, np.float32, 1, 2, 0, 4, f0=f0, fmg=2)
+    want = O.cycle3d(n3, rg, mode=1, v0=2, v1=1, v2=2, f=f0, dtype=np.float32)
     assert bits_equal(got, want)
 
 
