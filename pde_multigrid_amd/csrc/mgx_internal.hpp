@@ -21,7 +21,8 @@ struct mgx_ctx {
     int relax_wave_planes = 0;  // time-skewed slab height of relax3d_xsplit: 0 off (measured slower: the L2-miss path, not HBM, is the limit), <0 automatic
     int relax_small = 1;   // levels <= 17^3: all sweeps of a Relax call in one workgroup (LDS resident)
     int relax_ablate = 0;  // diagnostic kernel variants (tools only)
-    int rr_stream = 1;     // x-split residual+restrict: streaming shuffle kernel (1) or LDS window kernel (0)
+    int rr_stream = 3;     // x-split residual+restrict: 0 LDS window kernel, 1 streaming shuffle kernel, 2 pipelined kernel,
+                           // 3 = pipelined on large levels, streaming otherwise
     int relax_lds = -1;  // smoother kernel choice: -1 automatic, 0 relax3d_xs_kernel, shape codes see relax3d_xs_pass_lds
     int rr_cr = 2, rr_tyw = 4;  // streaming residual+restrict: coarse rows per lane, waves per block
     int rr_pzchunk = 0;    // coarse planes per block of residual_restrict3d_kernel, 0 = automatic

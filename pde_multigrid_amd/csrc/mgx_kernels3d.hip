@@ -992,181 +992,140 @@ __global__ void __launch_bounds__(64 * TYW)
     }
 }
 
-// ------------------------------------------------------------------ residual + restrict, streaming, rows shared in LDS
-// residual_restrict3d_xs_kernel re-reads three of a lane's seven fine rows of v (and one of its five rows of f) that
-// the next row group also reads, and the PMC counters show those re-reads all reach the fabric (3.76 GB for 2.16 GB
-// of v and f at 513^3).  Here the TYW waves of a workgroup (adjacent row groups) load only the four rows they own;
-// rows 4..6 of v and rows 4..5 of f come from the wave below through LDS (the last wave of the workgroup loads
-// them).  Same software pipeline as relax3d_xs_pipe_kernel: in the step of fine plane g a wave takes delivery of
-// what it requested a step earlier (its rows of v at plane g+1 and of f at plane g), requests plane g+2 / g+1,
-// publishes, meets the other waves at ONE barrier, reads the neighbour's rows and computes the residual of plane g.
-// Lanes 0 and 63 are halo lanes (they supply the x-1 residuals of lane 1 and the x+1 value of lane 62): a wave
-// produces 62 coarse columns and no lane loads anything but its own column.  Per-point expressions and the
-// association of the 27-point sum are those of residual_restrict3d_xs_kernel.
+// ------------------------------------------------------------------ residual + restrict, pipelined, halos through LDS
+// The recipe of relax3d_xs_pipe_kernel applied to residual+restrict.  residual_restrict3d_xs_kernel keeps a 7-row
+// window per lane and re-reads three of the seven rows of v (and one of five of f) that the next row group also
+// reads; those re-reads all reach the fabric (PMC: 3.76 GB for 2.16 GB of v and f at 513^3), also when the waves are
+// kept in lock-step by a barrier -- the caches do not merge them.  Here a wave owns FOUR fine rows (two coarse rows)
+// and loads nothing else: the row above and the row below its four come from the neighbouring waves of the
+// workgroup through LDS (v of the current plane), and so does the residual row the second coarse row needs from
+// below (the next wave's first row).  The last wave of a workgroup is a halo wave: it supplies those rows to the wave
+// above it and produces no output (it loads two rows of v and one of f), so a workgroup of TYW waves produces
+// 2 (TYW-1) coarse rows.  Software pipeline as in the smoother: in the step of fine plane g a wave requests v of
+// plane g+2 and f of plane g+1, publishes its edge rows of plane g+1, reads its neighbours' edge rows of plane g,
+// computes the residual of plane g, publishes the residual of its first row, and meets the others at ONE barrier;
+// what it requested is waited for only after the barrier.  The coarse plane pz is formed at the start of the step
+// after its third residual plane (2pz+1), when the neighbour's residual rows are visible.  Lanes 0 and 63 are halo
+// lanes (62 coarse columns per wave, nobody loads a foreign column).  Expressions and association: those of
+// residual_restrict3d_xs_kernel.
+template <class real>
+__device__ __forceinline__ real wave_from_prev_lane(real x) {  // lane i gets lane i-1 (lane 0 keeps its own)
+    if constexpr (sizeof(real) == 8) {
+        int lo = __double2loint(x), hi = __double2hiint(x);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xf, 0xf, false));
+    }
+}
+template <class real>
+__device__ __forceinline__ real wave_from_next_lane(real x) {  // lane i gets lane i+1 (lane 63 keeps its own)
+    if constexpr (sizeof(real) == 8) {
+        int lo = __double2loint(x), hi = __double2hiint(x);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130, 0xf, 0xf, false));
+    }
+}
+
 template <class real, int MODE, int TYW>
 __global__ void __launch_bounds__(64 * TYW)
     residual_restrict3d_xs_pipe_kernel(const real* __restrict__ v, const real* __restrict__ f, int sx, int sy, int szg,
                                        real hx2, real hy2, real hz2, real* __restrict__ coarse, int cx, int cy, int czg,
                                        int pzchunk, int fzoff, int czoff, int pzbeg, int pzend) {
-    constexpr int CR = 2, NR = 7, OWN = 4;
-    __shared__ real sv[2][TYW][3][2][64];  // [slot][wave][row 0..2][A / B][lane]: v of plane g+1
-    __shared__ real sf[2][TYW][2][2][64];  // [slot][wave][row 0..1][A / B][lane]: f of plane g
+    constexpr int OWN = 4;
+    __shared__ real hv[2][TYW][2][2][64];  // [plane & 1][wave][first / last own row][A / B][lane]: v
+    __shared__ real hr[4][TYW][2][64];     // [plane & 3][wave][A / B][lane]: residual of the wave's first own row
     const Geo<XSplit, real> gf(sx, sy), gc(cx, cy);
     const int lane = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int in = blockIdx.x * 62 + lane;  // nominal coarse column; lanes past the row are clamped and masked
     const int i = min(in, cx - 1);
-    const int cyb = 1 + (blockIdx.y * TYW + w) * CR;
-    const bool wave_on = cyb <= cy - 2;                       // waves past the last coarse row only keep the barriers company
-    const bool lastw = w == TYW - 1 || cyb + CR > cy - 2;     // no active wave below in this workgroup
+    const int cyb = 1 + (blockIdx.y * (TYW - 1) + w) * 2;  // this wave's coarse rows: cyb, cyb + 1
+    const bool halo_wave = w == TYW - 1;                   // supplies rows to the wave above, produces nothing
     int pz0 = pzbeg + blockIdx.z * pzchunk;
     const int pz1 = min(min(pz0 + pzchunk, pzend), czg - 1);
     if (pz0 < 1) pz0 = 1;
     if (pz0 >= pz1) return;  // uniform over the workgroup
-    const bool hasB = i <= cx - 2;                            // the odd-x entry 2i+1 exists
-    const bool xinA = in >= 1 && in <= cx - 2;                // x = 2i is interior (and the lane is inside the row)
-    const bool validB = in <= cx - 2 && lane < 63;            // lane 63 has no x+1 neighbour: its B residual is not used
-    const bool produces = xinA && lane >= 1 && lane <= 62 && wave_on;
-    const int yf0 = 2 * cyb - 2;
-    int roff[NR];
-    bool yin[NR];
+    const bool hasB = i <= cx - 2;
+    const bool xinA = in >= 1 && in <= cx - 2;
+    const bool validB = in <= cx - 2 && lane < 63;
+    const bool produces = !halo_wave && xinA && lane >= 1 && lane <= 62;
+    const int Y0 = 2 * cyb - 1;  // first own fine row
+    int roff[OWN];
+    bool yin[OWN];
 #pragma unroll
-    for (int r = 0; r < NR; r++) {
-        const int y = yf0 + r;
-        roff[r] = min(y, sy - 1) * gf.P;
-        yin[r] = y >= 1 && y <= sy - 2;
+    for (int o = 0; o < OWN; o++) {
+        roff[o] = min(Y0 + o, sy - 1) * gf.P;
+        yin[o] = Y0 + o <= sy - 2;  // Y0 >= 1
     }
+    const int roffU = min(Y0 - 1, sy - 1) * gf.P;  // the row above (loaded by the first wave of the workgroup only)
+    const int nv = halo_wave ? 2 : OWN, nf = halo_wave ? 1 : OWN;  // rows of v / f this wave loads
     const int PL = (int)gf.PL;
     const int offA = i, offB = gf.H + (hasB ? i : 0);
-    // residuals of fine plane g on rows 1 .. 5 for x = 2i (rA) and x = 2i+1 (rB); 0 outside the interior
-    auto resid = [&](const real (&AP)[NR], const real (&BP)[NR], const real (&AC)[NR], const real (&BC)[NR],
-                     const real (&AN)[NR], const real (&BN)[NR], const real (&fA)[NR], const real (&fB)[NR],
-                     real (&rA)[NR - 2], real (&rB)[NR - 2]) __attribute__((always_inline)) {
+    const int wU = w > 0 ? w - 1 : 0, wD = w < TYW - 1 ? w + 1 : TYW - 1;
+
+    real AP[OWN], BP[OWN], AC[OWN], BC[OWN], AN[OWN], BN[OWN], AX[OWN], BX[OWN], fA[OWN], fB[OWN], fAX[OWN], fBX[OWN];
+    real rAm[OWN], rBm[OWN], rA0[OWN], rB0[OWN], rAp[OWN], rBp[OWN];
+    real tAc = 0, tBc = 0, tAx = 0, tBx = 0;  // the row above, planes g / g+1 (first wave only)
+    const int g0 = 2 * pz0 - 1, glast = 2 * pz1 - 1;
+    const real* pv = v + (size_t)(g0 - fzoff) * gf.PL;  // plane g of v and f, advanced with g
+    const real* pf = f + (size_t)(g0 - fzoff) * gf.PL;
 #pragma unroll
-        for (int r = 1; r < NR - 1; r++) {
-            const real Bl = __shfl_up(BC[r], 1, 64);    // v(2i-1): odd entry of lane i-1
-            const real Ar = __shfl_down(AC[r], 1, 64);  // v(2i+2): even entry of lane i+1
-            const real a = residual3d_point<real, MODE>(Bl, BC[r], AC[r - 1], AC[r + 1], AP[r], AN[r], AC[r], fA[r], hx2, hy2, hz2);
-            const real b = residual3d_point<real, MODE>(AC[r], Ar, BC[r - 1], BC[r + 1], BP[r], BN[r], BC[r], fB[r], hx2, hy2, hz2);
-            rA[r - 1] = (yin[r] && xinA && lane > 0) ? a : (real)0;
-            rB[r - 1] = (yin[r] && validB) ? b : (real)0;
+    for (int o = 0; o < OWN; o++) {
+        AP[o] = BP[o] = AC[o] = BC[o] = AN[o] = BN[o] = AX[o] = BX[o] = fA[o] = fB[o] = fAX[o] = fBX[o] = 0;
+        rAm[o] = rBm[o] = rA0[o] = rB0[o] = rAp[o] = rBp[o] = 0;
+        if (o < nv) {
+            AP[o] = pv[roff[o] - PL + offA];
+            BP[o] = pv[roff[o] - PL + offB];
+            AC[o] = pv[roff[o] + offA];
+            BC[o] = pv[roff[o] + offB];
+            AN[o] = pv[roff[o] + PL + offA];
+            BN[o] = pv[roff[o] + PL + offB];
         }
-    };
-    real AP[NR], BP[NR], AC[NR], BC[NR], AN[NR], BN[NR], AX[NR], BX[NR], fA[NR], fB[NR], fAX[OWN], fBX[OWN];
-    real rAm[NR - 2], rBm[NR - 2], rA0[NR - 2], rB0[NR - 2], rAp[NR - 2], rBp[NR - 2];
-    // prologue (no sharing yet): v planes 2pz0-2, 2pz0-1, 2pz0 and f of plane 2pz0-1 on all rows, residual of 2pz0-1
-    {
-        const real* p0 = v + (size_t)(2 * pz0 - 2 - fzoff) * gf.PL;
-        const real* q1 = f + (size_t)(2 * pz0 - 1 - fzoff) * gf.PL;
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            AP[r] = p0[roff[r] + offA];
-            BP[r] = p0[roff[r] + offB];
-            AC[r] = p0[PL + roff[r] + offA];
-            BC[r] = p0[PL + roff[r] + offB];
-            AN[r] = p0[2 * PL + roff[r] + offA];
-            BN[r] = p0[2 * PL + roff[r] + offB];
-            fA[r] = q1[roff[r] + offA];
-            fB[r] = q1[roff[r] + offB];
-            AX[r] = BX[r] = 0;
+        if (o < nf) {
+            fA[o] = pf[roff[o] + offA];
+            fB[o] = pf[roff[o] + offB];
         }
-        resid(AP, BP, AC, BC, AN, BN, fA, fB, rAm, rBm);
-#pragma unroll
-        for (int r = 0; r < NR; r++) { AP[r] = AC[r]; BP[r] = BC[r]; AC[r] = AN[r]; BC[r] = BN[r]; }
     }
-    // plane pointers of the next requests: v at plane gq+1, f at plane gq, gq = the plane of the coming step
-    const real* pvn = v + (size_t)(2 * pz0 + 1 - fzoff) * gf.PL;
-    const real* pfn = f + (size_t)(2 * pz0 - fzoff) * gf.PL;
-    auto request = [&]() __attribute__((always_inline)) {  // own rows (and the shared rows, for the last wave) of v / f
+    if (w == 0) {
+        tAc = pv[roffU + offA];
+        tBc = pv[roffU + offB];
+    }
+    hv[g0 & 1][w][0][0][lane] = AC[0];
+    hv[g0 & 1][w][0][1][lane] = BC[0];
+    hv[g0 & 1][w][1][0][lane] = AC[OWN - 1];
+    hv[g0 & 1][w][1][1][lane] = BC[OWN - 1];
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // coarse plane pz from the residual planes 2pz-1, 2pz, 2pz+1 = (m, 0, p) and the next wave's first row (LDS ring)
+    auto form_coarse = [&](int pz) __attribute__((always_inline)) {
+        const int gm = 2 * pz - 1;
+        real sa[OWN + 1], sb[OWN + 1], sc[OWN + 1];
 #pragma unroll
-        for (int r = 0; r < OWN; r++) {
-            AX[r] = pvn[roff[r] + offA];
-            BX[r] = pvn[roff[r] + offB];
-            fAX[r] = pfn[roff[r] + offA];
-            fBX[r] = pfn[roff[r] + offB];
+        for (int o = 0; o < OWN; o++) {
+            const real lm = wave_from_prev_lane<real>(rBm[o]), l0 = wave_from_prev_lane<real>(rB0[o]),
+                       lp = wave_from_prev_lane<real>(rBp[o]);
+            sa[o] = rA0[o];
+            sb[o] = ((rAp[o] + rB0[o]) + rAm[o]) + l0;  // (N + E + S + O): (x,z+1), (x+1,z), (x,z-1), (x-1,z)
+            sc[o] = ((rBp[o] + rBm[o]) + lm) + lp;      // (NE + SE + SO + NO)
         }
-        if (lastw) {
-#pragma unroll
-            for (int r = OWN; r < NR; r++) {
-                AX[r] = pvn[roff[r] + offA];
-                BX[r] = pvn[roff[r] + offB];
-            }
-            // f rows 4, 5 travel in the slots of v rows that are not needed above the residual rows: AX/BX have no
-            // row 7, so they get their own two registers
-        }
-        pvn += PL;
-        pfn += PL;
-    };
-    real fA45[2], fB45[2], fAX45[2] = {0, 0}, fBX45[2] = {0, 0};
-    auto request_f45 = [&](const real* pf_plane) __attribute__((always_inline)) {
-        if (lastw) {
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                fAX45[k] = pf_plane[roff[OWN + k] + offA];
-                fBX45[k] = pf_plane[roff[OWN + k] + offB];
-            }
-        }
-    };
-    // one fine plane: on entry AP / AC hold planes g-1 / g, AX + fAX what was requested for g+1 / g
-    auto step = [&](bool more, real (&rA)[NR - 2], real (&rB)[NR - 2], int g) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the requests of the previous step
-#pragma unroll
-        for (int r = 0; r < NR; r++) { AN[r] = AX[r]; BN[r] = BX[r]; }
-#pragma unroll
-        for (int r = 0; r < OWN; r++) { fA[r] = fAX[r]; fB[r] = fBX[r]; }
-        fA45[0] = fAX45[0]; fA45[1] = fAX45[1]; fB45[0] = fBX45[0]; fB45[1] = fBX45[1];
-        if (more) {
-            request_f45(pfn);
-            request();
-        }
-        const int slot = g & 1;
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            sv[slot][w][r][0][lane] = AN[r];
-            sv[slot][w][r][1][lane] = BN[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            sf[slot][w][r][0][lane] = fA[r];
-            sf[slot][w][r][1][lane] = fB[r];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (!lastw) {
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                AN[OWN + r] = sv[slot][w + 1][r][0][lane];
-                BN[OWN + r] = sv[slot][w + 1][r][1][lane];
-            }
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                fA[OWN + r] = sf[slot][w + 1][r][0][lane];
-                fB[OWN + r] = sf[slot][w + 1][r][1][lane];
-            }
-        } else {
-            fA[OWN] = fA45[0]; fA[OWN + 1] = fA45[1]; fB[OWN] = fB45[0]; fB[OWN + 1] = fB45[1];
-        }
-        fA[NR - 1] = fB[NR - 1] = 0;  // row 6 has no residual
-        resid(AP, BP, AC, BC, AN, BN, fA, fB, rA, rB);
-#pragma unroll
-        for (int r = 0; r < NR; r++) { AP[r] = AC[r]; BP[r] = BC[r]; AC[r] = AN[r]; BC[r] = BN[r]; }
-    };
-    request_f45(pfn);
-    request();
-    for (int pz = pz0; pz < pz1; pz++) {
-        step(true, rA0, rB0, 2 * pz);                  // plane 2pz (requests plane 2pz+2 of v, 2pz+1 of f)
-        step(pz + 1 < pz1, rAp, rBp, 2 * pz + 1);      // plane 2pz+1
-        // per-row sub-sums a, b, c of residual rows 0 .. 4 (x-1 values: rB of lane i-1)
-        real sa[NR - 2], sb[NR - 2], sc[NR - 2];
-#pragma unroll
-        for (int r = 0; r < NR - 2; r++) {
-            const real lm = __shfl_up(rBm[r], 1, 64), l0 = __shfl_up(rB0[r], 1, 64), lp = __shfl_up(rBp[r], 1, 64);
-            sa[r] = rA0[r];
-            sb[r] = ((rAp[r] + rB0[r]) + rAm[r]) + l0;      // (N + E + S + O): (x,z+1), (x+1,z), (x,z-1), (x-1,z)
-            sc[r] = ((rBp[r] + rBm[r]) + lm) + lp;          // (NE + SE + SO + NO)
+        {   // the row below my four: the first row of the next wave
+            const int lm1 = lane > 0 ? lane - 1 : 0;
+            const real eAm = hr[gm & 3][wD][0][lane], eBm = hr[gm & 3][wD][1][lane], elm = hr[gm & 3][wD][1][lm1];
+            const real eA0 = hr[(gm + 1) & 3][wD][0][lane], eB0 = hr[(gm + 1) & 3][wD][1][lane], el0 = hr[(gm + 1) & 3][wD][1][lm1];
+            const real eAp = hr[(gm + 2) & 3][wD][0][lane], eBp = hr[(gm + 2) & 3][wD][1][lane], elp = hr[(gm + 2) & 3][wD][1][lm1];
+            sa[OWN] = eA0;
+            sb[OWN] = ((eAp + eB0) + eAm) + el0;
+            sc[OWN] = ((eBp + eBm) + elm) + elp;
         }
         if (produces) {
 #pragma unroll
-            for (int c = 0; c < CR; c++) {
+            for (int c = 0; c < 2; c++) {
                 const int py = cyb + c;
                 if (py <= cy - 2) {
                     const int rn = 2 * c, rc = 2 * c + 1, rs = 2 * c + 2;
@@ -1176,9 +1135,72 @@ __global__ void __launch_bounds__(64 * TYW)
                 }
             }
         }
+    };
+
+    for (int g = g0; g <= glast; g++) {
+        const bool more = g < glast;
+        if (more) {  // requests for the next step: v of plane g+2, f of plane g+1, the row above at plane g+1
 #pragma unroll
-        for (int r = 0; r < NR - 2; r++) { rAm[r] = rAp[r]; rBm[r] = rBp[r]; }
+            for (int o = 0; o < OWN; o++) {
+                if (o < nv) {
+                    AX[o] = pv[roff[o] + 2 * PL + offA];
+                    BX[o] = pv[roff[o] + 2 * PL + offB];
+                }
+                if (o < nf) {
+                    fAX[o] = pf[roff[o] + PL + offA];
+                    fBX[o] = pf[roff[o] + PL + offB];
+                }
+            }
+            if (w == 0) {
+                tAx = pv[roffU + PL + offA];
+                tBx = pv[roffU + PL + offB];
+            }
+            const int s1 = (g + 1) & 1;  // edge rows of plane g+1 for the neighbours' next step
+            hv[s1][w][0][0][lane] = AN[0];
+            hv[s1][w][0][1][lane] = BN[0];
+            hv[s1][w][1][0][lane] = AN[OWN - 1];
+            hv[s1][w][1][1][lane] = BN[OWN - 1];
+        }
+        if (!(g & 1) && g >= 2 * pz0 + 2) form_coarse(g / 2 - 1);  // its three residual planes are g-3, g-2, g-1
+        // neighbours' edge rows of plane g
+        const int s0 = g & 1;
+        const real upA = w > 0 ? hv[s0][wU][1][0][lane] : tAc, upB = w > 0 ? hv[s0][wU][1][1][lane] : tBc;
+        const real dnA = hv[s0][wD][0][0][lane], dnB = hv[s0][wD][0][1][lane];
+        real rAn[OWN], rBn[OWN];
+#pragma unroll
+        for (int o = 0; o < OWN; o++) {
+            const real Bl = wave_from_prev_lane<real>(BC[o]);  // v(2i-1): odd entry of lane i-1
+            const real Ar = wave_from_next_lane<real>(AC[o]);  // v(2i+2): even entry of lane i+1
+            const real An = o == 0 ? upA : AC[o > 0 ? o - 1 : 0], As = o == OWN - 1 ? dnA : AC[o < OWN - 1 ? o + 1 : o];
+            const real Bn = o == 0 ? upB : BC[o > 0 ? o - 1 : 0], Bs = o == OWN - 1 ? dnB : BC[o < OWN - 1 ? o + 1 : o];
+            const real a = residual3d_point<real, MODE>(Bl, BC[o], An, As, AP[o], AN[o], AC[o], fA[o], hx2, hy2, hz2);
+            const real b = residual3d_point<real, MODE>(AC[o], Ar, Bn, Bs, BP[o], BN[o], BC[o], fB[o], hx2, hy2, hz2);
+            rAn[o] = (yin[o] && xinA && lane > 0) ? a : (real)0;
+            rBn[o] = (yin[o] && validB) ? b : (real)0;
+        }
+        hr[g & 3][w][0][lane] = rAn[0];
+        hr[g & 3][w][1][lane] = rBn[0];
+#pragma unroll
+        for (int o = 0; o < OWN; o++) {
+            rAm[o] = rA0[o]; rBm[o] = rB0[o];
+            rA0[o] = rAp[o]; rB0[o] = rBp[o];
+            rAp[o] = rAn[o]; rBp[o] = rBn[o];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this step's requests have had the whole step
+#pragma unroll
+        for (int o = 0; o < OWN; o++) {
+            AP[o] = AC[o]; BP[o] = BC[o];
+            AC[o] = AN[o]; BC[o] = BN[o];
+            AN[o] = AX[o]; BN[o] = BX[o];
+            fA[o] = fAX[o]; fB[o] = fBX[o];
+        }
+        tAc = tAx;
+        tBc = tBx;
+        pv += PL;
+        pf += PL;
     }
+    form_coarse(pz1 - 1);  // the last coarse plane of the run (its third residual plane was the last step)
 }
 
 // ------------------------------------------------------------------ sum of squares
@@ -1530,12 +1552,17 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
         MGX_HIP(hipMemsetAsync(coarse_f + gc.PL * (size_t)(pzbeg - czoff), 0, gc.PL * (size_t)(pzend - pzbeg) * sizeof(real),
                                ctx->compute));
     if (cn[0] < 3 || cn[1] < 3) return MGX_OK;
-    if (ctx->rr_stream == 2) {  // rows shared through LDS, software-pipelined (residual_restrict3d_xs_pipe_kernel)
-        const int T = ctx->rr_tyw == 8 ? 8 : (ctx->rr_tyw == 2 ? 2 : 4);
-        const int gx = ceil_div(cn[0] - 2, 62), gy = ceil_div(cn[1] - 2, 2 * T);
+    // rr_stream 3 (default): the pipelined kernel with 8-wave workgroups on levels of at least 513 x 129 rows and 8
+    // coarse planes -- measured -4 ... -8 % there (513^3, 1025^3; PMC 3.10 instead of 3.76 GB), not at 257^3
+    const bool big = n[0] >= 513 && n[1] >= 129 && pzend - pzbeg >= 8;
+    if (ctx->rr_stream == 2 || (ctx->rr_stream == 3 && big)) {  // residual_restrict3d_xs_pipe_kernel
+        const int T = ctx->rr_stream == 3 ? 8 : (ctx->rr_tyw == 8 ? 8 : (ctx->rr_tyw == 2 ? 2 : 4));
+        const int gx = ceil_div(cn[0] - 2, 62), gy = ceil_div(cn[1] - 2, 2 * (T - 1));  // the last wave is a halo wave
         int pzc = ctx->rr_pzchunk;
         if (pzc <= 0) {
-            const int tiles = gx * gy, target = 2 * ctx->num_cus;
+            // about three resident rounds of workgroups (240 VGPRs: one 8-wave workgroup per CU at a time); the count is
+            // rounded to whole rounds because all workgroups take the same time (513^3: 95 tiles x 8 runs of 32 planes)
+            const int tiles = gx * gy, target = 3 * ctx->num_cus;
             const int nchunks = max(1, (target + tiles / 2) / tiles);
             pzc = max(4, ceil_div(pzend - pzbeg, nchunks));
         }
@@ -1918,8 +1945,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "residual_restrict3d.tyw")) {
         ctx->rr_tyw = value;  // waves per block: 2, 4 or 8
     } else if (!strcmp(name, "residual_restrict3d.stream")) {
-        ctx->rr_stream = value < 0 || value > 2 ? 1 : value;  // 0 = LDS rolling-window kernel, 1 = streaming shuffle kernel,
-                                                              // 2 = streaming with rows shared through LDS, pipelined (x-split)
+        ctx->rr_stream = value < 0 || value > 3 ? 3 : value;  // 0 = LDS rolling-window kernel, 1 = streaming shuffle kernel,
+                                                              // 2 = pipelined with halos through LDS (x-split), 3 = 2 on large levels, else 1 (default)
     } else if (!strcmp(name, "residual_restrict3d.pzchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "residual_restrict3d.pzchunk must be >= 0 (0 = automatic)");
         ctx->rr_pzchunk = value;

@@ -98,8 +98,8 @@ def test_3d_smallest_grid_and_zero_sweeps(ctx, layout):
     assert_f64(ops.residual(ctx, v, f, n3, rg), O.residual3d(n3, rg, v, f, dtype=np.float64))
 
 
-@pytest.mark.parametrize("n3", [(9, 9, 9), (33, 17, 65), (129, 65, 17), (257, 33, 9), (513, 9, 17)])
-@pytest.mark.parametrize("stream", [0, 1, 2])
+@pytest.mark.parametrize("n3", [(9, 9, 9), (33, 17, 65), (129, 65, 17), (257, 33, 9), (513, 9, 17), (513, 129, 17)])
+@pytest.mark.parametrize("stream", [0, 1, 2, 3])
 def test_3d_xsplit_residual_restrict_variants(ctx, n3, stream):
     """the x-split residual+restrict kernels (LDS rolling window / streaming shuffles / streaming with the shared rows
     handed over through LDS) == oracle, all chunkings and workgroup heights"""
@@ -118,7 +118,7 @@ def test_3d_xsplit_residual_restrict_variants(ctx, n3, stream):
                         ctx.set_param("residual_restrict3d.tyw", tyw)
                         assert bits_equal(P.ops3dxs.residual_restrict(ctx, v, f, n3, rg, mode), want), (dtype, mode, chunk, tyw)
     finally:
-        ctx.set_param("residual_restrict3d.stream", 1)
+        ctx.set_param("residual_restrict3d.stream", 3)
         ctx.set_param("residual_restrict3d.pzchunk", 0)
         ctx.set_param("residual_restrict3d.tyw", 4)
 
