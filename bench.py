@@ -202,7 +202,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as O  # CPU baseline leg only: the checker timed as a reported baseline
-            cn, clev, reps = 257, 6, 3
+            cn, clev, reps = 257, 6, 12  # about 10 s of single-threaded CPU work
             secs = O.time_vcycle3d(cn, clev, args.v1, args.v2, reps, dtype)
             c_lups = (args.v1 + args.v2) * sum((s - 2) ** 3 for s in level_sizes(cn, clev)) * reps
             out["cpu_baseline"] = {
