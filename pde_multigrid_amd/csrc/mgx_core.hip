@@ -12,6 +12,29 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// zero fill at streaming-store speed: hipMemsetAsync reaches about 2.8 TB/s on large arrays, 16-byte non-temporal
+// stores about twice that (the coarse v of every level is zeroed once per cycle)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) fill_zero_kernel(u32x4* __restrict__ p, size_t n16) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(z, &p[i]);
+}
+
+int fill_zero(mgx_ctx* ctx, void* dst, size_t bytes) {
+    if (!bytes) return MGX_OK;
+    if (bytes < ((size_t)4 << 20) || ((uintptr_t)dst & 15) || (bytes & 15)) {
+        MGX_HIP(hipMemsetAsync(dst, 0, bytes, ctx->compute));
+        return MGX_OK;
+    }
+    const size_t n16 = bytes >> 4;
+    size_t blocks = (n16 + 256 * 8 - 1) / (256 * 8);  // 8 stores per thread
+    const size_t cap = (size_t)ctx->num_cus * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->compute, (u32x4*)dst, n16);
+    MGX_HIP(hipGetLastError());
+    return MGX_OK;
+}
+
 int workspace(mgx_ctx* ctx, size_t bytes, void** out) {
     if (ctx->scratch_bytes < bytes) {
         if (ctx->scratch) {
@@ -169,9 +192,7 @@ int mgx_memcpy_d2d(mgx_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 int mgx_memset_zero(mgx_ctx* ctx, void* dst, size_t bytes) {
     MGX_REQUIRE(ctx && (bytes == 0 || dst), MGX_ERR_INVALID, "NULL argument");
-    if (!bytes) return MGX_OK;
-    MGX_HIP(hipMemsetAsync(dst, 0, bytes, ctx->compute));
-    return MGX_OK;
+    return mgx::fill_zero(ctx, dst, bytes);
 }
 
 int mgx_graph_begin(mgx_ctx* ctx) {

@@ -54,6 +54,7 @@ inline int fail(int status, const char* fmt, ...) {
 
 // workspace of at least `bytes` (grown on demand; contents undefined)
 int workspace(mgx_ctx* ctx, size_t bytes, void** out);
+int fill_zero(mgx_ctx* ctx, void* dst, size_t bytes);  // dst[0, bytes) := 0 on the compute stream
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
@@ -75,3 +76,8 @@ inline bool valid_size(int n) { return n >= 3 && ((n - 1) % 2 == 0); }
     } while (0)
 
 #define MGX_LAUNCH_CHECK() MGX_HIP(hipGetLastError())
+#define MGX_TRY_RET(expr)            \
+    do {                             \
+        const int st_ = (expr);      \
+        if (st_) return st_;         \
+    } while (0)

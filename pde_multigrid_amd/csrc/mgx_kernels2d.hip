@@ -366,8 +366,7 @@ int set2d(mgx_ctx* ctx, real* g, const int n[2], real value, int modify_boundari
     if (st) return st;
     const int lo = modify_boundaries ? 0 : 1;
     if (modify_boundaries && value == (real)0 && !std::signbit(value)) {  // the cycle's "coarse v := 0" (:326)
-        MGX_HIP(hipMemsetAsync(g, 0, (size_t)n[0] * n[1] * sizeof(real), ctx->compute));
-        return MGX_OK;
+        return fill_zero(ctx, g, (size_t)n[0] * n[1] * sizeof(real));
     }
     hipLaunchKernelGGL((set2d_kernel<real>), grd2(n[0] - 2 * lo, n[1] - 2 * lo), blk2(), 0, ctx->compute, g, n[0], n[1],
                        value, lo);

@@ -1516,8 +1516,7 @@ int set3d(mgx_ctx* ctx, real* g, const int n[3], real value, int modify_boundari
         // the cycle's "coarse v := 0" (N3/MultiGrid3D.cpp:634): +0.0 is all-zero bits, the pad entries of the x-split
         // layout are zero by invariant -> one fill of the whole array at memset speed
         const size_t elems = Geo<L, real>(n[0], n[1]).PL * (size_t)n[2];  // natural layout: PL = n[0] * n[1]
-        MGX_HIP(hipMemsetAsync(g, 0, elems * sizeof(real), ctx->compute));
-        return MGX_OK;
+        return fill_zero(ctx, g, elems * sizeof(real));
     }
     hipLaunchKernelGGL((set3d_kernel<real, L>), grd(n[0] - 2 * lo, n[1] - 2 * lo, n[2] - 2 * lo), blk(), 0, ctx->compute, g,
                        n[0], n[1], n[2], value, lo);
@@ -1549,8 +1548,7 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
     // the kernels write every interior coarse point of the planes and nothing else: boundary points and pad entries
     // are zeroed here unless the caller vouches that they already are (they stay zero from one cycle to the next)
     if (!rim_is_zero)
-        MGX_HIP(hipMemsetAsync(coarse_f + gc.PL * (size_t)(pzbeg - czoff), 0, gc.PL * (size_t)(pzend - pzbeg) * sizeof(real),
-                               ctx->compute));
+        MGX_TRY_RET(fill_zero(ctx, coarse_f + gc.PL * (size_t)(pzbeg - czoff), gc.PL * (size_t)(pzend - pzbeg) * sizeof(real)));
     if (cn[0] < 3 || cn[1] < 3) return MGX_OK;
     // rr_stream 3 (default): the pipelined kernel with 8-wave workgroups on levels of at least 513 x 129 rows and 8
     // coarse planes -- measured -4 ... -8 % there (513^3, 1025^3; PMC 3.10 instead of 3.76 GB), not at 257^3
