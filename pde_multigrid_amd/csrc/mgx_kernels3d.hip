@@ -19,8 +19,12 @@
 //
 // Kernels (reference function each one replaces):
 //   relax3d_colour_kernel     one colour of MultiGrid3D::Relax, Natural   N3/MultiGrid3D.cpp:489-567
-//   relax3d_xs_kernel         one colour of MultiGrid3D::Relax, XSplit, z-marching with
-//                             register reuse of the z-1 / z / z+1 column values
+//   relax3d_xs_pipe_kernel    one colour of MultiGrid3D::Relax, XSplit: THE hot kernel (levels >= 257 rows wide).
+//                             One workgroup per CU marches a long run of planes; neighbours' edge rows / lanes
+//                             through LDS, loads one plane ahead, stores one plane behind, one barrier per plane
+//   relax3d_xs_kernel         the same pass with many small workgroups and re-loaded edges (smaller levels,
+//                             thin z-ranges); relax3d_xs_lds_kernel: LDS edges without the software pipeline (A/B)
+//   relax3d_small_kernel      all sweeps of a Relax call on a level <= 17^3 in one workgroup (LDS resident)
 //   residual3d_kernel         MultiGrid3D::CalculateResidual          N3/MultiGrid3D.cpp:678-730
 //   restrict3d_kernel         MultiGrid3D::Restrict                   N3/MultiGrid3D.cpp:50-184
 //   interpolate3d_kernel      MultiGrid3D::Interpolate (+ApplyCorrection when ADD)
@@ -28,7 +32,10 @@
 //   correct3d_kernel          MultiGrid3D::ApplyCorrection            N3/MultiGrid3D.cpp:649-676
 //   set3d_kernel              MultiGrid3D::setToValue                 N3/MultiGrid3D.cpp:587-621
 //   init_f3d_kernel           Grid3D::InitF                           N3/Grid3D.cpp:78-96
-//   residual_restrict3d_kernel  CalculateResidual + Restrict fused through LDS
+//   residual_restrict3d_xs_pipe_kernel / _xs_kernel / residual_restrict3d_kernel
+//                             CalculateResidual + Restrict fused (no residual array): pipelined with LDS halos
+//                             (large levels) / streaming register window / LDS rolling window (Natural)
+//   interpolate3d_xs_kernel   Interpolate (+ApplyCorrection, optionally one colour only), XSplit
 //   relayout3d_kernel         Natural <-> XSplit (upload / download of the hierarchy)
 #include "mgx_internal.hpp"
 #include "mgx_kernels3d.hpp"
