@@ -24,7 +24,7 @@ struct mgx_ctx {
     int rr_stream = 3;     // x-split residual+restrict: 0 LDS window kernel, 1 streaming shuffle kernel, 2 pipelined kernel,
                            // 3 = pipelined on large levels, streaming otherwise
     int relax_lds = -1;  // smoother kernel choice: -1 automatic, 0 relax3d_xs_kernel, shape codes see relax3d_xs_pass_lds
-    int rr_cr = 2, rr_tyw = 4;  // streaming residual+restrict: coarse rows per lane, waves per block
+    int rr_cr = 0, rr_tyw = 4;  // streaming residual+restrict: coarse rows per lane, waves per block
     int rr_pzchunk = 0;    // coarse planes per block of residual_restrict3d_kernel, 0 = automatic
     void* scratch = nullptr;  // small device workspace (reductions, tables)
     size_t scratch_bytes = 0;

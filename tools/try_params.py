@@ -18,7 +18,7 @@ ctx = P.Context(0)
 mg = P.MultiGrid3D(ctx, [n] * 3, [0, 1, 0, 1, 0, 1], np.float64, nlevels=2)
 e0, e1 = ctx.event(), ctx.event()
 base = {"relax3d.ty": 4, "relax3d.rows": 4, "relax3d.zchunk": 0, "relax3d.xcd": 1, "relax3d.ablate": 0, "relax3d.lds": -1,
-        "residual_restrict3d.stream": 3, "residual_restrict3d.pzchunk": 0, "residual_restrict3d.cr": 2,
+        "residual_restrict3d.stream": 3, "residual_restrict3d.pzchunk": 0, "residual_restrict3d.cr": 0,
         "residual_restrict3d.tyw": 4}
 res = {a: [] for a in args}
 rr = {a: [] for a in args}
