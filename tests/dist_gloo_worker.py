@@ -18,7 +18,7 @@ import pde_multigrid_amd as P  # noqa: E402
 R3 = [0, 1, 0, 1, 0, 1]
 
 
-def _rank_main(rank, world, port, n, v1, v2, cycles, min_planes, mode, out_path):
+def _rank_main(rank, world, port, n, v1, v2, cycles, min_planes, mode, out_path, fmg_v0=0):
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -130,6 +130,45 @@ def _rank_main(rank, world, port, n, v1, v2, cycles, min_planes, mode, out_path)
             exchange_v(l)
         relax(l, v2)
 
+    def fmg(l):  # mgDistMultiGrid3D_FullMultiGridVCycle (csrc/host/mg_dist3d.inc) on a distributed level
+        p = plans[l]
+        s3 = [sizes[l]] * 3
+        N = sizes[l] - 1
+        cN = sizes[l + 1] - 1
+        czlo = p.zlo // 2
+        pzint = min(p.zhi, N) // 2
+        poison(f[l], p)
+        cf = O.restrict3d(s3, f[l], dtype)  # Restrict(f): the owned coarse planes read the f ghost below
+        if l + 1 < ndist:
+            czhi = sizes[l + 1] if rank == world - 1 else p.zhi // 2
+            f[l + 1][:] = np.nan
+            f[l + 1][czlo:czhi] = cf[czlo:czhi]
+            exchange_f_up(l + 1)
+            fmg(l + 1)
+            cv = v[l + 1].copy()
+            poison(cv, plans[l + 1])
+        else:
+            share = cN // world
+            mine = torch.from_numpy(np.ascontiguousarray(cf[czlo:czlo + share]))
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            tf = np.zeros((sizes[l + 1],) * 3, dtype)
+            tf[:cN] = np.concatenate([q.numpy() for q in parts], axis=0)
+            top = torch.from_numpy(np.ascontiguousarray(cf[cN:cN + 1]))  # the injected boundary plane: valid on the last rank
+            tops = [torch.empty_like(top) for _ in range(world)]
+            dist.all_gather(tops, top)
+            tf[cN:] = tops[world - 1].numpy()
+            cv = O.cycle3d([sizes[l + 1]] * 3, R3, nlevels=numGrids - ndist, mode=1, v0=fmg_v0, v1=v1, v2=v2,
+                           v=np.zeros_like(tf), f=tf, residual_mode=mode, dtype=dtype)
+        e = O.interpolate3d(s3, v[l], cv, dtype)  # plain Interpolate: interior of the fine planes of my coarse cells
+        lo, hi = max(2 * czlo, 1), 2 * pzint
+        v[l][lo:hi] = e[lo:hi]
+        exchange_v(l)
+        for _ in range(fmg_v0):
+            vcycle(l)
+
+    if fmg_v0:
+        fmg(0)
     for _ in range(cycles):
         vcycle(0)
     p = plans[0]
@@ -141,4 +180,5 @@ def _rank_main(rank, world, port, n, v1, v2, cycles, min_planes, mode, out_path)
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    _rank_main(int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), int(a[6]), int(a[7]), int(a[8]), a[9])
+    _rank_main(int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), int(a[6]), int(a[7]), int(a[8]), a[9],
+               int(a[10]) if len(a) > 10 else 0)

@@ -51,6 +51,24 @@ def test_slab_plan_world2_matches_single_domain(tmp_path, n, min_planes, mode):
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
 
 
+@pytest.mark.parametrize("n,min_planes,mode", [(33, 4, O.REF_COMPAT), (33, 2, O.CORRECT)])
+def test_slab_fmg_world2_matches_single_domain(tmp_path, n, min_planes, mode):
+    """FullMultiGridVCycle on slabs: Restrict(f) with the ghost below, the replicated tail's f by all-gather (its top
+    boundary plane from the last rank), plain Interpolate + ghost exchange on the way up"""
+    world, v0, v1, v2 = 2, 1, 2, 2
+    out = str(tmp_path / "slab%d.npy")
+    port = _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gloo_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker] + [str(a) for a in (r, world, port, n, v1, v2, 0, min_planes, mode, out, v0)])
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.concatenate([np.load(out % r) for r in range(world)], axis=0)
+    want = O.cycle3d([n] * 3, R3, mode=1, v0=v0, v1=v1, v2=v2, residual_mode=mode, dtype=np.float64)
+    assert not np.isnan(got).any()
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
 def test_plan_invariants():
     for world in (1, 2, 4, 8):
         for n in (33, 65, 513, 1025):
