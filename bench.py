@@ -1,27 +1,40 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """bench.py -- MLUPS of the 3D Poisson V(2,2) cycle on MI355X, with the smoother's HBM roofline.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 may be started either by a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or plainly: without WORLD_SIZE in the environment
+this process only counts the devices (it never initialises the GPU, never imports libmgx and never exec's) and starts
+the N ranks itself as fresh child processes through `python -m torch.distributed.run`, then exits with their code.
 
 Workload
   N = 1 : BASELINE.json configs[3]: 3D Poisson, 513 points per axis ("512^3"), fp64, native 9-level
           hierarchy, analytic RHS of the reference (Grid3D::InitF), v = 0, reference (REF_COMPAT) semantics.
   N > 1 : BASELINE.json configs[4]: the same problem at 1025 points per axis ("1024^3"), ONE hierarchy
           decomposed into z-slabs over the N GPUs (ghost planes over RCCL/xGMI, coarse levels replicated after an
-          all-gather) -- strong scaling: the total work does not depend on N.  `--n` overrides the size.
+          all-gather) -- strong scaling: the total work does not depend on N.  `--size` overrides the size.
 One step = one VCycle(0, 2, 2) through the C host layer (include/mg_multigrid.h), inputs resident in HBM.
     MLUPS = (v1+v2) * sum_levels (n_l - 2)^3 * steps / seconds          
 roofline: the dominant kernel is the red-black Gauss-Seidel smoother on the finest level; its algorithmic
     traffic is 3 reals per lattice update per red+black sweep = 24 B/LUP in fp64 (12 B per LUP of one colour
     launch).  `achieved` = algorithmic bytes per launch / average launch duration, measured here with HIP events
     on the stream the kernel runs on, over a smoother-only timed region (rank 0's slab when N > 1, without the
-    ghost exchange).
-cpu_baseline: the oracle's CPU restatement ("port": same loop nest and single thread as the reference) timed
-    on this box's host cores on a bounded sample, rank 0 at N = 1 only.
+    ghost exchange).  `kernel` is the name the library reports for the launch; `traffic` (HBM bytes per launch from
+    separate rocprofv3 --pmc passes, profiles/pmc_traffic.json) is attached only when it was taken from that kernel.
+result check: after the timed regions one more cycle is run from v = 0 and the finest v is compared with the
+    committed known answer of the oracle (tests/golden/known_answers_f64.json: a position-weighted 64-bit checksum
+    that numpy can evaluate); on a mismatch NO metric line is printed (exit 3).
+cpu_baseline: the NOCUDA_TESI CPU path on this box's host cores, 1 thread, bounded sample, rank 0 at N = 1 only:
+    the compiled reference itself (oracle/_ref, kind "reference") when it travelled with the repo, else the
+    oracle's restatement (kind "port"); both optimisation levels (the reference's own CompileAndLink uses none),
+    V(2,2) on 257^3 (6 levels) and the smoother on 513^3, plus the restatement/reference time ratio.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,6 +53,93 @@ def level_sizes(n, nlevels):
     return out
 
 
+def checksum(a, first_word=0):
+    """(sum w_i, sum w_i * (2 i + 1)) mod 2^64 over the words of `a` (64-bit words for fp64, 32-bit for fp32) in
+    memory order, i counted from `first_word` (so that slabs of one array can be summed separately and added) --
+    the same function as oracle/gen_known_f64.py, restated here because the product side of the bench does not
+    import oracle/"""
+    import numpy as np
+    w = np.ascontiguousarray(a).reshape(-1)
+    w = w.view(np.uint64) if w.dtype.itemsize == 8 else w.view(np.uint32)
+    s1, s2, step = np.uint64(0), np.uint64(0), 1 << 24
+    with np.errstate(over="ignore"):
+        for i in range(0, w.size, step):
+            c = w[i:i + step].astype(np.uint64)
+            k = np.arange(first_word + i, first_word + i + c.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+            s1 = s1 + c.sum(dtype=np.uint64)
+            s2 = s2 + (c * k).sum(dtype=np.uint64)
+    return int(s1), int(s2)
+
+
+def known_answer(n, nlev, dtype):
+    path = os.path.join(ROOT, "tests", "golden", "known_answers_f64.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh).get("3d_n%d_vcycle22_%dlev_%s" % (n, nlev, dtype))
+
+
+def spawn_ranks(args):
+    """parent of a plain `bench.py --gpus N`: start the ranks as fresh children BEFORE anything touches the GPU here"""
+    import torch  # device_count() does not initialise the GPU on this image
+    found = torch.cuda.device_count()
+    if found < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d needs %d GPUs, found %d\n" % (args.gpus, args.gpus, found))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(args, dtype):
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O  # CPU baseline leg only: the checker timed as a reported baseline
+    import refshim as RS
+    cn, clev = 257, 6
+    c_lups = (args.v1 + args.v2) * sum((s - 2) ** 3 for s in level_sizes(cn, clev))
+    s_lups = (513 - 2) ** 3
+    legs = {}
+
+    def leg(name, secs, lups):
+        legs[name] = {"seconds": round(secs, 3), "mlups": round(lups / secs / 1e6, 2)}
+        return legs[name]["mlups"]
+
+    have_ref = RS.available("O2") and RS.available("O0")
+    # the restatement (same loop nest as the reference, float = the reference's type), both optimisation levels
+    leg("port_f32_O2_vcycle257", O.time_vcycle3d(cn, clev, args.v1, args.v2, 1, np.float32, "O2"), c_lups)
+    leg("port_f32_O0_vcycle257", O.time_vcycle3d(cn, clev, args.v1, args.v2, 1, np.float32, "O0"), c_lups)
+    leg("port_f32_O2_relax513", O.time_relax3d(513, 1, np.float32, "O2"), s_lups)
+    leg("port_%s_O2_vcycle257" % args.dtype, O.time_vcycle3d(cn, clev, args.v1, args.v2, 2, dtype, "O2") / 2, c_lups)
+    if have_ref:
+        value = leg("reference_f32_O2_vcycle257", RS.time_vcycle3d(cn, clev, args.v1, args.v2, 1, "O2"), c_lups)
+        leg("reference_f32_O0_vcycle257", RS.time_vcycle3d(cn, clev, args.v1, args.v2, 1, "O0"), c_lups)
+        leg("reference_f32_O2_relax513", RS.time_relax3d(513, 1, "O2"), s_lups)
+        leg("reference_f32_O0_relax513", RS.time_relax3d(513, 1, "O0"), s_lups)
+        kind = "reference"
+        what = "the compiled NOCUDA_TESI reference (oracle/_ref, fp32, g++ -O2; the -O0 legs are what its own CompileAndLink builds)"
+        ratio = round(legs["port_f32_O2_vcycle257"]["seconds"] / legs["reference_f32_O2_vcycle257"]["seconds"], 3)
+    else:
+        leg("port_f32_O0_relax513", O.time_relax3d(513, 1, np.float32, "O0"), s_lups)
+        value = legs["port_f32_O2_vcycle257"]["mlups"]
+        kind = "port"
+        what = "the oracle's CPU restatement of the reference (fp32, g++ -O2, reference loop nest)"
+        ratio = None
+    total = sum(v["seconds"] for v in legs.values())
+    return {
+        "value": value, "unit": "MLUPS", "cores": 1, "kind": kind,
+        "sample": "1 V(%d,%d) cycle, 3D Poisson %d^3 fp32, %d levels, %s, 1 thread of %d host cores; all legs %.1f s"
+                  % (args.v1, args.v2, cn, clev, what, os.cpu_count() or 0, total),
+        "legs": legs,
+        "port_over_reference_time": ratio,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,21 +154,25 @@ def main():
                     help="N>1: a level stays distributed while every GPU owns this many planes; coarser levels are replicated "
                          "(below about 32 planes per GPU the ghost exchanges are pure latency)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the result check against the committed known answer")
+    ap.add_argument("--no-one-gpu-leg", action="store_true", help="N>1: skip rank 0's single-GPU run of the same problem")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
 
     # MGX_BENCH_FORCE_DIST=1 runs the slab-decomposed code path (torch rendezvous, RCCL communicator, slab
     # hierarchy) even with one rank: a plumbing check for boxes with a single GPU
     force_dist = os.environ.get("MGX_BENCH_FORCE_DIST", "0") == "1"
+    slabbed = world > 1 or force_dist
     dist = None
-    if world > 1 or force_dist:
+    if slabbed:
         # torch BEFORE libmgx (pde_multigrid_amd/_lib.py: load order of the ROCm runtime libraries)
         import torch
         import torch.distributed as dist  # control plane only (rendezvous, barrier, max over ranks); data plane = RCCL in libmgx
@@ -83,7 +187,7 @@ def main():
     n = args.n or (513 if world == 1 else 1025)
     ctx = P.Context(local_rank)
 
-    if world == 1 and not force_dist:
+    if not slabbed:
         mg = P.MultiGrid3D(ctx, [n] * 3, R3, dtype)
         reset = lambda: mg.setToValue_v(0, 0.0, True)  # noqa: E731
         nd = 0
@@ -124,7 +228,7 @@ def main():
     # ---- smoother-only region for the roofline (HIP events on the compute stream) -------
     reset()
     e0, e1 = ctx.event(), ctx.event()
-    if world == 1 and not force_dist:
+    if not slabbed:
         # the smoother exactly as the cycle calls it: Relax(grid, v1) = v1 red-black sweeps per call
         mg.Relax(0, args.v1)
         ctx.sync()
@@ -134,7 +238,7 @@ def main():
         ctx.record(e1)
         args.smoother_sweeps = (args.smoother_sweeps // max(args.v1, 1)) * max(args.v1, 1)
         my_lups_per_launch = (n - 2) ** 3 / 2.0
-        kname = "relax3d_xs_pipe_kernel<%s,2,8,2> (finest level, x-split layout, one colour per launch)"
+        where = "finest level, x-split layout, one colour per launch"
     else:
         for c in (0, 1):
             mg.relax_colour_local(0, c)
@@ -146,7 +250,8 @@ def main():
         ctx.record(e1)
         p = mg.plan(0)
         my_lups_per_launch = (n - 2) ** 2 * (p.uend - p.ubeg) / 2.0
-        kname = "relax3d_xs_pipe_kernel<%s,2,8,2> (finest level, rank 0's z-slab, one colour per launch, ghost exchange excluded)"
+        where = "finest level, rank 0's z-slab, one colour per launch, ghost exchange excluded"
+    kname = ctx.last_relax_kernel()
     ms = ctx.elapsed_ms(e0, e1)
     launches = 2 * args.smoother_sweeps  # one launch per colour
     bytes_per_launch = 3 * wbytes * my_lups_per_launch  # 24 B/LUP fp64 per red+black sweep, half the points per colour launch
@@ -154,6 +259,75 @@ def main():
     achieved = bytes_per_launch / launch_s
     smoother_mlups = 2 * my_lups_per_launch * args.smoother_sweeps / (ms * 1e-3) / 1e6
     barrier()
+
+    # ---- result check: one cycle from v = 0 against the oracle's committed known answer ----
+    check = None
+    if not args.no_check and args.v1 == 2 and args.v2 == 2:
+        ka = known_answer(n, nlev, args.dtype)
+        reset()
+        mg.VCycle(0, 2, 2)
+        centre = None
+        if not slabbed:
+            got = mg.download_v(0)
+            s1, s2 = checksum(got)
+            centre = float(got[n // 2, n // 2, n // 2])
+        else:
+            # every rank sums the planes it owns (word index = position in the whole array); rank 0 adds the parts
+            pl = mg.plan(0)
+            got = mg.download_owned(0)
+            s1, s2 = checksum(got, pl.zlo * n * n)
+            if pl.zlo <= n // 2 < pl.zhi:
+                centre = float(got[n // 2 - pl.zlo, n // 2, n // 2])
+            if world > 1:
+                parts = [None] * world
+                dist.all_gather_object(parts, (s1, s2, centre))
+                s1 = sum(q[0] for q in parts) & ((1 << 64) - 1)
+                s2 = sum(q[1] for q in parts) & ((1 << 64) - 1)
+                centre = [q[2] for q in parts if q[2] is not None][0]
+        del got
+        if rank == 0:
+            s1, s2 = "%016x" % s1, "%016x" % s2
+            if ka is None:
+                check = {"status": "no known answer committed for this size / dtype", "n": n, "dtype": args.dtype}
+            else:
+                ok = s1 == ka["sum64"] and s2 == ka["wsum64"]
+                check = {"status": "ok" if ok else "MISMATCH",
+                         "known_answer": "tests/golden/known_answers_f64.json: 3d_n%d_vcycle22_%dlev_%s" % (n, nlev, args.dtype),
+                         "sum64": s1, "wsum64": s2, "centre": centre}
+                if not ok:
+                    sys.stderr.write("bench.py: RESULT CHECK FAILED -- the cycle's result differs from the oracle's known answer: %s "
+                                     "(expected sum64 %s wsum64 %s centre %r); no metric is reported\n"
+                                     % (json.dumps(check), ka["sum64"], ka["wsum64"], ka["centre"]))
+    failed = [check is not None and check.get("status") == "MISMATCH"]
+    if dist is not None:
+        dist.broadcast_object_list(failed, src=0)
+    if failed[0]:
+        mg.close()
+        ctx.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        sys.exit(3)
+
+    # ---- N > 1: the same problem on ONE GPU (rank 0, the others wait), for the strong-scaling factor ----
+    one_gpu = None
+    if world > 1 and not args.no_one_gpu_leg:
+        if rank == 0:
+            ctx1 = P.Context(local_rank)
+            mg1 = P.MultiGrid3D(ctx1, [n] * 3, R3, dtype)
+            k1 = max(2, min(args.steps, 5))
+            mg1.VCycle(0, args.v1, args.v2)
+            ctx1.sync()
+            ta = time.perf_counter()
+            for _ in range(k1):
+                mg1.VCycle(0, args.v1, args.v2)
+            ctx1.sync()
+            tb = time.perf_counter()
+            mg1.close()
+            ctx1.close()
+            one_gpu = {"ms_per_step": round((tb - ta) / k1 * 1e3, 4), "steps": k1,
+                       "speedup": round(((tb - ta) / k1) / (elapsed / args.steps), 3),
+                       "note": "the same %d^3 hierarchy on rank 0's GPU alone, timed in this run while the other ranks wait" % n}
+        dist.barrier()
 
     if rank == 0:
         out = {
@@ -172,17 +346,17 @@ def main():
             "config": {
                 "workload": "3D Poisson %d^3 points (%d^3 cells), %s, V(%d,%d) cycle, %d levels%s"
                             % (n, n - 1, args.dtype, args.v1, args.v2, nlev,
-                               "" if world == 1 else ", one hierarchy in %d z-slabs" % world),
+                               "" if not slabbed else ", one hierarchy in %d z-slab%s" % (world, "s" if world > 1 else "")),
                 "levels": sizes,
                 "lups_per_cycle": lups_per_cycle,
-                "parallelism": "single GPU" if world == 1 else
-                               "z-slab decomposition over %d GPUs: %d distributed levels (ghost planes over RCCL), %d replicated"
-                               % (world, nd, nlev - nd),
+                "parallelism": "single GPU" if not slabbed else
+                               "z-slab decomposition over %d GPU%s: %d distributed levels (ghost planes over RCCL), %d replicated"
+                               % (world, "s" if world > 1 else "", nd, nlev - nd),
                 "note": "N=1 runs BASELINE configs[3] (513^3); N>1 runs configs[4] (1025^3) as one strong-scaled problem",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": kname % ("double" if wbytes == 8 else "float"),
+                "kernel": "%s (%s)" % (kname, where),
                 "achieved": round(achieved / 1e9, 1),
                 "peak": HBM_PEAK_BPS / 1e9,
                 "unit": "GB/s",
@@ -192,28 +366,23 @@ def main():
                 "avg_launch_us": round(launch_s * 1e6, 2),
                 "smoother_mlups_this_gpu": round(smoother_mlups, 1),
             },
+            "result_check": check,
         }
+        if one_gpu is not None:
+            out["config"]["one_gpu_same_problem"] = one_gpu
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if world == 1 and n == 513 and args.dtype == "f64" and os.path.exists(pmc):
-            # HBM bytes per launch of the same kernel from the separate rocprofv3 --pmc passes (tools/pmc_summary.py):
-            # 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md
+        if not slabbed and n == 513 and args.dtype == "f64" and os.path.exists(pmc):
+            # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_summary.py): 2 x FETCH_SIZE +
+            # WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md -- only if they were taken from the kernel that ran
             with open(pmc) as fh:
-                out["roofline"]["traffic"] = json.load(fh).get("smoother_f64_513_bytes_per_launch")
-        if world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle as O  # CPU baseline leg only: the checker timed as a reported baseline
-            cn, clev, reps = 257, 6, 12  # about 10 s of single-threaded CPU work
-            secs = O.time_vcycle3d(cn, clev, args.v1, args.v2, reps, dtype)
-            c_lups = (args.v1 + args.v2) * sum((s - 2) ** 3 for s in level_sizes(cn, clev)) * reps
-            out["cpu_baseline"] = {
-                "value": round(c_lups / secs / 1e6, 2),
-                "unit": "MLUPS",
-                "cores": 1,
-                "kind": "port",
-                "sample": "%d V(%d,%d) cycles, 3D Poisson %d^3 %s, %d levels, oracle CPU restatement (-O2, reference loop "
-                          "nest, 1 thread of %d host cores), %.1f s" % (reps, args.v1, args.v2, cn, args.dtype, clev,
-                                                                         os.cpu_count() or 0, secs),
-            }
+                t = json.load(fh)
+            if t.get("kernel_name") == kname:
+                out["roofline"]["traffic"] = t.get("smoother_f64_513_bytes_per_launch")
+            else:
+                out["roofline"]["traffic_note"] = ("profiles/pmc_traffic.json was taken from %r, not from the kernel that ran"
+                                                   % t.get("kernel_name"))
+        if world == 1 and not slabbed and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, dtype)
         print(json.dumps(out))
     mg.close()
     ctx.close()

@@ -51,6 +51,7 @@ int mg_dist_num_levels_single(int sizeZ_finest, int numGrids, int min_planes);
 int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
 
 #define MG_MAX_LEVELS 32 /* (int)log2(size-1) of any int size */
+#define MG_NORM_HISTORY 255 /* residual-norm history entries a distributed hierarchy keeps on the device */
 #define MG_DECLARE(R, real)                                                                              \
     /* ------------------------------------------------------------------ 3D ------ */                  \
     typedef struct mgGrid3D_##R {                                                                        \
@@ -143,6 +144,8 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         int residual_mode;                                                                               \
         real* d_share;             /* staging for the agglomeration all-gather */                        \
         real* d_bplane;            /* FMG: staging for the top boundary plane of the replicated f */     \
+        double* d_norm;            /* device: [0] scratch of ResidualNorm, [1 ...] squared-norm history */ \
+        int norm_count;            /* entries recorded by ResidualNormRecord (<= MG_NORM_HISTORY) */     \
     } mgDistMultiGrid3D_##R;                                                                             \
     int mgDistMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6], \
                                        int min_planes, mgDistMultiGrid3D_##R** out);                     \
@@ -153,6 +156,16 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
     /* FullMultiGridVCycle (N3/MultiGrid3D.cpp:569-585) on slabs                                        */ \
     int mgDistMultiGrid3D_##R##_FullMultiGridVCycle(mgDistMultiGrid3D_##R* mg, int gridID, int v0,       \
                                                     int v1, int v2);                                     \
+    /* l2 norm of the residual of a distributed level over the WHOLE grid (ADDITION: the reference has  */ \
+    /* no norm; parity unpinned): every rank reduces the squared residual of the planes  */ \
+    /* it owns on the device (wavefront-wide shuffles, fixed order), the partial sums are all-reduced   */ \
+    /* over RCCL (one double) and every rank returns the same value.  Blocking.  Uses residual_mode.    */ \
+    int mgDistMultiGrid3D_##R##_ResidualNorm(mgDistMultiGrid3D_##R* mg, int gridID, double* l2);         \
+    /* the same without a host round trip: the squared norm is appended to a history kept on the device */ \
+    /* (at most MG_NORM_HISTORY entries, e.g. one per cycle); _History downloads sqrt of the entries.    */ \
+    int mgDistMultiGrid3D_##R##_ResidualNormRecord(mgDistMultiGrid3D_##R* mg, int gridID);               \
+    int mgDistMultiGrid3D_##R##_ResidualNormHistory(mgDistMultiGrid3D_##R* mg, double* host_l2,          \
+                                                    int capacity, int* count);                          \
     int mgDistMultiGrid3D_##R##_zero_v(mgDistMultiGrid3D_##R* mg, int gridID);                           \
     int mgDistMultiGrid3D_##R##_upload_v(mgDistMultiGrid3D_##R* mg, int gridID, const real* host_full);  \
     int mgDistMultiGrid3D_##R##_upload_f(mgDistMultiGrid3D_##R* mg, int gridID, const real* host_full);  \

@@ -84,6 +84,9 @@ int mgx_ctx_device(const mgx_ctx* ctx, int* device);
  * planes per block (0 = automatic); "relax3d.xcd" 0/1/2 block-to-tile mapping (2 = every XCD owns a y-slab and walks z);
  * "relax3d.wave_planes" slab height of the time-skewed pass order (< 0 automatic, 0 = whole-grid passes) */
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value);
+/* name (kernel<template arguments>) of the smoother kernel the most recent 3D x-split colour pass launched; "" if none.
+ * bench.py reports it as roofline.kernel so that the PMC traffic figure is attached only to the kernel it was taken from */
+const char* mgx_ctx_last_relax_kernel(const mgx_ctx* ctx);
 /* raw hipStream_t of the compute stream (for callers that bring their own HIP code) */
 int mgx_ctx_stream(const mgx_ctx* ctx, void** hip_stream);
 
@@ -211,6 +214,12 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                                              const int n[3], int fzoff, const real h[3], int mode,      \
                                              real* coarse_f, const int cn[3], int czoff, int pzbeg,     \
                                              int pzend);                                                \
+    /* residual_sumsq_slab (ADDITION, the reference has no norm): sum of the squared residual over the */ \
+    /* (x, y)-interior points of the local planes [zbeg, zend) -> *dev_out (device double), async on   */ \
+    /* the compute stream, reduced in a fixed order (same bits on every run)                           */ \
+    int mgx3dxs_residual_sumsq_slab_##SFX(mgx_ctx* ctx, const real* v, const real* f, int sx, int sy,   \
+                                          const real h[3], int mode, int zbeg, int zend,                \
+                                          double* dev_out);                                             \
     /* FMG on slabs: Restrict (coarse planes [pzbeg, pzend); boundary points by injection) and plain  */ \
     /* Interpolate (fine planes 2pz, 2pz+1 of every listed pz, interior points, z = 0 skipped).       */ \
     /* setToValue(.., false) on the LOCAL planes [zbeg, zend) of a slab: their (x, y)-interior points  */ \
@@ -271,12 +280,18 @@ int mgx_comm_unique_id(void* host_id_bytes);
 int mgx_comm_init(mgx_ctx* ctx, const void* host_id_bytes, int rank, int nranks);
 int mgx_comm_destroy(mgx_ctx* ctx);
 int mgx_comm_rank(const mgx_ctx* ctx, int* rank, int* nranks);
-/* Test transport: `nranks` host threads of one process, one context each, all on the same device;
- * device-to-device copies and a pthread barrier stand in for RCCL so that the slab-decomposed cycle
- * can be verified on a single-GPU box.  Every rank's thread must take part in every exchange. */
+/* Test transport: `nranks` host threads of one process, one context each, all on the same device, so that the
+ * slab-decomposed cycle AND the event ordering of its overlap schedule can be verified on a single-GPU box.  Same
+ * stream semantics as RCCL: an exchange only enqueues device-to-device copies on the comm stream, ordered against
+ * the peers by cross-context events; nothing is synchronised by the host; the compute stream sees the result only
+ * through mgx_comm_wait.  Every rank's thread must take part in every exchange (as with RCCL).
+ * _set_test_hooks: delay_us > 0 starts every transfer that late on the receiving comm stream (a missing wait then
+ * reads stale ghosts for certain); drop_waits != 0 turns mgx_comm_wait into a no-op for the group's contexts (fault
+ * injection: the tests must notice).  The hooks exist on this test transport only. */
 typedef struct mgx_local_group mgx_local_group;
 int mgx_local_group_create(int nranks, mgx_local_group** out);
 int mgx_local_group_destroy(mgx_local_group* group);
+int mgx_local_group_set_test_hooks(mgx_local_group* group, int delay_us, int drop_waits);
 int mgx_comm_init_local(mgx_ctx* ctx, mgx_local_group* group, int rank);
 /* Exchange ghost planes with the z-neighbours on a non-periodic chain of ranks (rank-1 = "lower",
  * rank+1 = "upper").  Counts are in elements of elem_bytes (4 or 8) and must match what the
@@ -287,8 +302,9 @@ int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_to_lower, size_t count
                            size_t count_from_lower, const void* send_to_upper, size_t count_to_upper,
                            void* recv_from_upper, size_t count_from_upper, int elem_bytes);
 int mgx_comm_wait(mgx_ctx* ctx);
-/* all-gather `count` reals per rank (agglomeration of a coarse level) and all-reduce one
- * double (residual norm).  Both enqueue on the comm stream with the same ordering rules. */
+/* all-gather `count` reals per rank (agglomeration of a coarse level) and all-reduce (sum, in place) of `count`
+ * doubles (residual norm; every rank receives the same bits).  Both enqueue on the comm stream with the same
+ * ordering rules, on both transports. */
 int mgx_comm_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count, int elem_bytes);
 int mgx_comm_allreduce_sum_f64(mgx_ctx* ctx, double* dev_inout, size_t count);
 /* RCCL plumbing check usable on a single-GPU box: this rank sends `count` doubles to itself with a grouped

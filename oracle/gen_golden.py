@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Generate tests/golden/ from the UNMODIFIED compiled reference -- container-only.
 
 Runs oracle/_ref/libmgref.so (= /root/reference's NOCUDA_TESI sources compiled in place by

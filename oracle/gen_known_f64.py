@@ -1,0 +1,70 @@
+"""Known answers of the fp64 BASELINE configurations from the oracle's CPU restatement -- TEST INFRASTRUCTURE.
+
+The reference is fp32 only, so the fp64 oracle is restatement<double> (pinned transitively: restatement<float> is
+bit-identical to the compiled reference, tests/test_oracle_vs_ref.py).  A 1025^3 cycle takes minutes and ~47 GB on the
+CPU, so its result is hashed once here and the GPU tests / bench.py compare against the committed values
+(tests/golden/known_answers_f64.json) instead of re-running the oracle on the GPU box.
+
+    python oracle/gen_known_f64.py [513] [1025]
+
+Per case: `fnv` = oracle.fnv of the finest v after ONE V(2,2) cycle from v = 0 (analytic RHS of Grid3D::InitF,
+reference residual semantics), `sum64` / `wsum64` = the position-weighted 64-bit checksum bench.py can evaluate
+with numpy alone (checksum64 below), `centre` = the centre value, `block_fnv` = fnv per block of 64 planes
+(to localise a mismatch).  InitF depends on libm's sin: valid for the glibc of this image (2.35).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import oracle as O  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "known_answers_f64.json")
+R3 = [0, 1, 0, 1, 0, 1]
+
+
+def checksum64(a):
+    """(sum w_i, sum w_i * (2 i + 1)) mod 2^64 over the 64-bit words of `a` in memory order"""
+    w = np.ascontiguousarray(a).reshape(-1).view(np.uint64)
+    s1 = np.uint64(0)
+    s2 = np.uint64(0)
+    step = 1 << 24
+    with np.errstate(over="ignore"):
+        for i in range(0, w.size, step):
+            c = w[i:i + step]
+            k = np.arange(i, i + c.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+            s1 = s1 + c.sum(dtype=np.uint64)
+            s2 = s2 + (c * k).sum(dtype=np.uint64)
+    return "%016x" % int(s1), "%016x" % int(s2)
+
+
+def case(n):
+    nlev = O.num_grids(n)
+    v = O.cycle3d([n] * 3, R3, mode=0, v1=2, v2=2, reps=1, dtype=np.float64)
+    s1, s2 = checksum64(v)
+    return {
+        "n": n, "nlevels": nlev, "v1": 2, "v2": 2, "dtype": "f64", "fnv": O.fnv(v), "sum64": s1, "wsum64": s2,
+        "centre": float(v[n // 2, n // 2, n // 2]),
+        "block_fnv": [O.fnv(v[z:z + 64]) for z in range(0, n, 64)],
+    }
+
+
+def main():
+    sizes = [int(a) for a in sys.argv[1:]] or [513, 1025]
+    data = {}
+    if os.path.exists(OUT):
+        with open(OUT) as fh:
+            data = json.load(fh)
+    for n in sizes:
+        key = "3d_n%d_vcycle22_%dlev_f64" % (n, O.num_grids(n))
+        data[key] = case(n)
+        print(key, data[key]["fnv"], data[key]["centre"], flush=True)
+        with open(OUT, "w") as fh:
+            json.dump(data, fh, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

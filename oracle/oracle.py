@@ -329,11 +329,25 @@ def cycle1d(n, rng, nlevels=0, mode=0, v0=1, v1=2, v2=2, reps=1, v=None, f=None,
 
 
 # ------------------------------------------------------------ cpu timers ---
-def time_relax3d(n, sweeps, dtype=np.float64):
-    s, _ = _sfx(dtype)
-    return getattr(lib(), "mgo3d_time_relax_" + s)(int(n), int(sweeps))
+LIB_PATH_O0 = os.path.join(_HERE, "libmgoracle_O0.so")  # the restatement without optimisation (the reference's own build uses no -O flag)
 
 
-def time_vcycle3d(n, nlevels, v1, v2, reps, dtype=np.float64):
+def _timer_lib(opt):
+    if opt == "O2":
+        return lib()
+    build()
+    so = C.CDLL(LIB_PATH_O0)
+    for nm in ("mgo3d_time_relax_f32", "mgo3d_time_relax_f64", "mgo3d_time_vcycle_f32", "mgo3d_time_vcycle_f64"):
+        getattr(so, nm).restype = C.c_double
+    return so
+
+
+def time_relax3d(n, sweeps, dtype=np.float64, opt="O2"):
     s, _ = _sfx(dtype)
-    return getattr(lib(), "mgo3d_time_vcycle_" + s)(int(n), int(nlevels), int(v1), int(v2), int(reps))
+    return getattr(_timer_lib(opt), "mgo3d_time_relax_" + s)(C.c_int(int(n)), C.c_int(int(sweeps)))
+
+
+def time_vcycle3d(n, nlevels, v1, v2, reps, dtype=np.float64, opt="O2"):
+    s, _ = _sfx(dtype)
+    return getattr(_timer_lib(opt), "mgo3d_time_vcycle_" + s)(C.c_int(int(n)), C.c_int(int(nlevels)), C.c_int(int(v1)),
+                                                               C.c_int(int(v2)), C.c_int(int(reps)))

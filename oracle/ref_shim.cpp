@@ -15,6 +15,7 @@
 // h_v / h_f arrays of the levels it needs with caller data, calls the public
 // member function, and copies the result out.  `nlevels > 0` overwrites the
 // public `numGrids` field.
+#include <chrono>
 #include <cstring>
 #include <cstdlib>
 #include <cstdint>
@@ -159,6 +160,33 @@ void ref3d_cycle(const int n[3], const float range[6], int nlevels, int mode, in
         mg.FullMultiGridVCycle(0, v0, v1, v2);
     }
     memcpy(v_out, g->h_v, N * sizeof(float));
+}
+
+// CPU-baseline timers (bench.py cpu_baseline, kind "reference"): the reference's own loops on its own analytic
+// problem ([0,1]^3), construction and InitF outside the timed region, one thread.
+double ref3d_time_vcycle(int n, int nlevels, int v1, int v2, int reps) {
+    int nn[3] = {n, n, n};
+    float rr[6] = {0, 1, 0, 1, 0, 1};
+    MultiGrid3D mg(nn, rr);
+    if (nlevels > 0) mg.numGrids = nlevels;
+    Grid3D* g = mg.grids3D[0];
+    mg.setToValue(g->h_v, g->sizeXYZ, 0.0f, false);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; i++) mg.VCycle(0, v1, v2);
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+double ref3d_time_relax(int n, int sweeps) {
+    int nn[3] = {n, n, n};
+    float rr[6] = {0, 1, 0, 1, 0, 1};
+    MultiGrid3D mg(nn, rr);
+    Grid3D* g = mg.grids3D[0];
+    mg.setToValue(g->h_v, g->sizeXYZ, 0.0f, false);
+    auto t0 = std::chrono::steady_clock::now();
+    mg.Relax(g, sweeps);
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count();
 }
 
 // ---------------------------------------------------------------- 2D ------

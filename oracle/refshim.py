@@ -13,10 +13,24 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_ref", "libmgref.so")
+LIB_PATH_O0 = os.path.join(_HERE, "_ref", "libmgref_O0.so")  # what the reference's own CompileAndLink builds (no -O flag)
 
 
-def available():
-    return os.path.exists(LIB_PATH)
+def available(opt="O2"):
+    return os.path.exists(LIB_PATH if opt == "O2" else LIB_PATH_O0)
+
+
+def time_vcycle3d(n, nlevels, v1, v2, reps, opt="O2"):
+    """seconds of `reps` x MultiGrid3D::VCycle(0, v1, v2) of the compiled reference (fp32, 1 thread); bench.py cpu_baseline"""
+    so = C.CDLL(LIB_PATH if opt == "O2" else LIB_PATH_O0)
+    so.ref3d_time_vcycle.restype = C.c_double
+    return so.ref3d_time_vcycle(C.c_int(n), C.c_int(nlevels), C.c_int(v1), C.c_int(v2), C.c_int(reps))
+
+
+def time_relax3d(n, sweeps, opt="O2"):
+    so = C.CDLL(LIB_PATH if opt == "O2" else LIB_PATH_O0)
+    so.ref3d_time_relax.restype = C.c_double
+    return so.ref3d_time_relax(C.c_int(n), C.c_int(sweeps))
 
 
 _lib = None

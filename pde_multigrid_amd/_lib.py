@@ -13,7 +13,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmgx.so")
+# tools/ may point this at the diagnostic twin (lib/libmgx_diag.so, `make -C pde_multigrid_amd/csrc diag`)
+LIB_PATH = os.environ.get("MGX_LIB_PATH") or os.path.join(_HERE, "lib", "libmgx.so")
 
 MGX_OK, MGX_ERR_INVALID, MGX_ERR_SIZE, MGX_ERR_HIP, MGX_ERR_NOMEM, MGX_ERR_RCCL, MGX_ERR_NOGPU = range(7)
 REF_COMPAT, CORRECT = 0, 1
@@ -35,6 +36,7 @@ lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
 lib.mgx_status_string.restype = C.c_char_p
 lib.mgx_last_error.restype = C.c_char_p
 lib.mgx_version.restype = C.c_char_p
+lib.mgx_ctx_last_relax_kernel.restype = C.c_char_p
 
 
 def status_string(status):

@@ -7,14 +7,24 @@
 // each over its own point-to-point xGMI link, issued on the context's comm stream so that
 // interior smoothing keeps running on the compute stream.
 //
-// Two transports behind the same entry points:
+// Two transports behind the same entry points, with the SAME stream semantics:
 //   RCCL   one process per GPU (mgx_comm_init): the production path
 //   local  several host threads of ONE process, one context each, all on the same device
-//          (mgx_comm_init_local): device-to-device copies and a pthread barrier.  It exists so
-//          that the slab-decomposed cycle can be checked bit-for-bit on a single-GPU box.
-#include <pthread.h>
+//          (mgx_comm_init_local).  It exists so that the slab-decomposed cycle -- including the event ordering
+//          of its overlap schedule -- can be checked bit-for-bit on a single-GPU box.  Like RCCL it is
+//          asynchronous: an exchange only ENQUEUES work on the comm stream (behind order_after_compute), peers
+//          are ordered by cross-context events (hipStreamWaitEvent on the neighbour's "planes posted" and
+//          "ghosts consumed" events), no stream is ever synchronised by the host, and the compute stream sees the
+//          result only through mgx_comm_wait.  The host threads rendezvous only to learn that a neighbour's
+//          event has been RECORDED (an event that was never recorded cannot be waited for); that is the job
+//          RCCL's proxy does.  Test hooks (mgx_local_group_set_test_hooks): a delay kernel in front of every
+//          transfer, so that a missing wait reads stale ghosts for certain, and a switch that turns
+//          mgx_comm_wait into a no-op, so that the tests can prove they would notice.
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 #include "mgx_internal.hpp"
@@ -31,14 +41,26 @@ static_assert(sizeof(ncclUniqueId) == MGX_UNIQUE_ID_BYTES, "MGX_UNIQUE_ID_BYTES 
 
 // shared state of a local (in-process) group
 struct mgx_local_group {
+    static constexpr int SLOTS = 2;  // event ring: exchange k uses slot k % SLOTS (see the reuse argument in local_begin)
     int nranks = 0;
-    pthread_barrier_t barrier;
-    struct Post {
-        const void* to_lower = nullptr;
-        const void* to_upper = nullptr;
-        const void* gather = nullptr;
+    std::mutex mu;
+    std::condition_variable cv;
+    struct Rank {
+        bool attached = false;
+        hipEvent_t ready[SLOTS] = {}, done[SLOTS] = {};
+        unsigned long long seq = 0;           // collectives this rank has started (only its own thread touches it)
+        unsigned long long posted_ready = 0;  // ... whose "posted" event is recorded           (guarded by mu)
+        unsigned long long posted_done = 0;   // ... whose "consumed" event is recorded          (guarded by mu)
+        const void* to_lower[SLOTS] = {};
+        const void* to_upper[SLOTS] = {};
+        const void* gather[SLOTS] = {};
+        double* red = nullptr;  // all-reduce staging: nranks x count doubles
+        size_t red_cap = 0;
     };
-    std::vector<Post> post;
+    std::vector<Rank> rank;
+    int delay_us = 0;    // test hook: every transfer starts this late on the receiving comm stream
+    int drop_waits = 0;  // test hook: mgx_comm_wait does nothing (fault injection for the negative test)
+    bool failed = false;
 };
 
 namespace {
@@ -52,19 +74,169 @@ int order_after_compute(mgx_ctx* ctx) {
 
 ncclDataType_t dtype_of(int elem_bytes) { return elem_bytes == 4 ? ncclFloat32 : ncclFloat64; }
 
+__global__ void delay_kernel(unsigned us) {  // wall_clock64 ticks at 100 MHz on gfx950
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(64);
+}
+
+__global__ void __launch_bounds__(256) sum_ranks_kernel(const double* __restrict__ parts, double* __restrict__ out, size_t count,
+                                                        int nranks) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double s = parts[i];  // fixed order: rank 0, 1, 2, ... -> every rank forms the same sum
+    for (int r = 1; r < nranks; r++) s += parts[(size_t)r * count + i];
+    out[i] = s;
+}
+
+// ---- the local transport ---------------------------------------------------------------------------------
+// Every collective of a rank has a sequence number k (all ranks issue the same collectives in the same order,
+// as with RCCL).  Rank r, collective k, slot s = k % SLOTS:
+//   1. comm_r waits for compute_r (order_after_compute); event ready[r][s] is recorded on comm_r ("my send
+//      planes are final"), the send pointers are posted, posted_ready[r] = k;
+//   2. the host thread waits until every peer p of this collective has posted_ready[p] >= k, then
+//      comm_r waits for ready[p][s] and the copies FROM the peers' send buffers are enqueued on comm_r;
+//   3. event done[r][s] is recorded on comm_r ("I have read my peers' planes"), posted_done[r] = k;
+//   4. the host thread waits until posted_done[p] >= k for every peer and makes comm_r wait for done[p][s]:
+//      like ncclSend, the exchange is complete on my comm stream only when my planes have been received.
+// Event reuse: ready[r][s] is re-recorded in collective k + SLOTS; every wait on its k-th recording was issued
+// in step 2 of a peer's collective k, which precedes that peer's posted_done = k, which rank r has seen in step 4
+// of its own collective k.  The same argument covers done[][] and the posted pointers.
+struct Peers {
+    int p[64];
+    int n = 0;
+};
+
+int wait_posted(mgx_local_group* g, const Peers& peers, unsigned long long k, bool done) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    for (;;) {
+        if (g->failed) return mgx::fail(MGX_ERR_RCCL, "local transport: another rank failed");
+        bool all = true;
+        for (int i = 0; i < peers.n; i++) {
+            const auto& q = g->rank[peers.p[i]];
+            if ((done ? q.posted_done : q.posted_ready) < k) all = false;
+        }
+        if (all) return MGX_OK;
+        if (g->cv.wait_until(lk, deadline) == std::cv_status::timeout) {
+            g->failed = true;
+            g->cv.notify_all();
+            return mgx::fail(MGX_ERR_RCCL, "local transport: a peer did not reach collective %llu (unbalanced schedule?)", k);
+        }
+    }
+}
+
+int local_begin(mgx_ctx* ctx, const Peers& peers, const void* to_lower, const void* to_upper, const void* gather,
+                unsigned long long* k_out) {
+    mgx_local_group* g = (mgx_local_group*)ctx->local_group;
+    auto& me = g->rank[ctx->rank];
+    const unsigned long long k = ++me.seq;
+    const int s = (int)(k % mgx_local_group::SLOTS);
+    MGX_TRY_RET(order_after_compute(ctx));
+    MGX_HIP(hipEventRecord(me.ready[s], ctx->comm));
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        me.to_lower[s] = to_lower;
+        me.to_upper[s] = to_upper;
+        me.gather[s] = gather;
+        me.posted_ready = k;
+    }
+    g->cv.notify_all();
+    MGX_TRY_RET(wait_posted(g, peers, k, false));
+    for (int i = 0; i < peers.n; i++) MGX_HIP(hipStreamWaitEvent(ctx->comm, g->rank[peers.p[i]].ready[s], 0));
+    if (g->delay_us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, ctx->comm, (unsigned)g->delay_us);
+    *k_out = k;
+    return MGX_OK;
+}
+
+int local_end(mgx_ctx* ctx, const Peers& peers, unsigned long long k) {
+    mgx_local_group* g = (mgx_local_group*)ctx->local_group;
+    auto& me = g->rank[ctx->rank];
+    const int s = (int)(k % mgx_local_group::SLOTS);
+    MGX_HIP(hipEventRecord(me.done[s], ctx->comm));
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        me.posted_done = k;
+    }
+    g->cv.notify_all();
+    MGX_TRY_RET(wait_posted(g, peers, k, true));
+    for (int i = 0; i < peers.n; i++) MGX_HIP(hipStreamWaitEvent(ctx->comm, g->rank[peers.p[i]].done[s], 0));
+    return MGX_OK;
+}
+
+Peers chain_peers(const mgx_ctx* ctx) {
+    Peers p;
+    if (ctx->rank > 0) p.p[p.n++] = ctx->rank - 1;
+    if (ctx->rank < ctx->nranks - 1) p.p[p.n++] = ctx->rank + 1;
+    return p;
+}
+
+Peers all_peers(const mgx_ctx* ctx) {
+    Peers p;
+    for (int r = 0; r < ctx->nranks; r++)
+        if (r != ctx->rank) p.p[p.n++] = r;
+    return p;
+}
+
 int local_halo(mgx_ctx* ctx, const void* send_lo, void* recv_lo, size_t n_from_lo, const void* send_up, void* recv_up,
                size_t n_from_up, int eb) {
     mgx_local_group* g = (mgx_local_group*)ctx->local_group;
-    MGX_HIP(hipStreamSynchronize(ctx->compute));  // my planes are final before a neighbour copies them
-    g->post[ctx->rank].to_lower = send_lo;
-    g->post[ctx->rank].to_upper = send_up;
-    pthread_barrier_wait(&g->barrier);
-    if (ctx->rank > 0 && n_from_lo)
-        MGX_HIP(hipMemcpyAsync(recv_lo, g->post[ctx->rank - 1].to_upper, n_from_lo * eb, hipMemcpyDeviceToDevice, ctx->comm));
-    if (ctx->rank < ctx->nranks - 1 && n_from_up)
-        MGX_HIP(hipMemcpyAsync(recv_up, g->post[ctx->rank + 1].to_lower, n_from_up * eb, hipMemcpyDeviceToDevice, ctx->comm));
-    MGX_HIP(hipStreamSynchronize(ctx->comm));
-    pthread_barrier_wait(&g->barrier);  // nobody overwrites a plane a neighbour is still reading
+    const Peers peers = chain_peers(ctx);
+    unsigned long long k = 0;
+    MGX_TRY_RET(local_begin(ctx, peers, send_lo, send_up, nullptr, &k));
+    const int s = (int)(k % mgx_local_group::SLOTS);
+    if (ctx->rank > 0 && n_from_lo) {
+        const void* src = g->rank[ctx->rank - 1].to_upper[s];
+        MGX_REQUIRE(src, MGX_ERR_INVALID, "halo exchange: the lower neighbour sends nothing up, but %zu elements are expected", n_from_lo);
+        MGX_HIP(hipMemcpyAsync(recv_lo, src, n_from_lo * eb, hipMemcpyDeviceToDevice, ctx->comm));
+    }
+    if (ctx->rank < ctx->nranks - 1 && n_from_up) {
+        const void* src = g->rank[ctx->rank + 1].to_lower[s];
+        MGX_REQUIRE(src, MGX_ERR_INVALID, "halo exchange: the upper neighbour sends nothing down, but %zu elements are expected", n_from_up);
+        MGX_HIP(hipMemcpyAsync(recv_up, src, n_from_up * eb, hipMemcpyDeviceToDevice, ctx->comm));
+    }
+    return local_end(ctx, peers, k);
+}
+
+int local_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count, int eb) {
+    mgx_local_group* g = (mgx_local_group*)ctx->local_group;
+    const Peers peers = all_peers(ctx);
+    unsigned long long k = 0;
+    MGX_TRY_RET(local_begin(ctx, peers, nullptr, nullptr, send, &k));
+    const int s = (int)(k % mgx_local_group::SLOTS);
+    for (int r = 0; r < ctx->nranks; r++) {
+        const void* src = r == ctx->rank ? send : g->rank[r].gather[s];
+        char* dst = (char*)recv + (size_t)r * count * eb;
+        if (src != dst) MGX_HIP(hipMemcpyAsync(dst, src, count * eb, hipMemcpyDeviceToDevice, ctx->comm));
+    }
+    return local_end(ctx, peers, k);
+}
+
+int local_allreduce(mgx_ctx* ctx, double* inout, size_t count) {
+    mgx_local_group* g = (mgx_local_group*)ctx->local_group;
+    auto& me = g->rank[ctx->rank];
+    const size_t need = (size_t)ctx->nranks * count;
+    if (me.red_cap < need) {
+        if (me.red) {
+            MGX_HIP(hipStreamSynchronize(ctx->comm));
+            MGX_HIP(hipFree(me.red));
+            me.red = nullptr;
+            me.red_cap = 0;
+        }
+        MGX_HIP(hipMalloc((void**)&me.red, need * sizeof(double)));
+        me.red_cap = need;
+    }
+    const Peers peers = all_peers(ctx);
+    unsigned long long k = 0;
+    MGX_TRY_RET(local_begin(ctx, peers, nullptr, nullptr, inout, &k));
+    const int s = (int)(k % mgx_local_group::SLOTS);
+    for (int r = 0; r < ctx->nranks; r++) {
+        const void* src = r == ctx->rank ? (const void*)inout : g->rank[r].gather[s];
+        MGX_HIP(hipMemcpyAsync(me.red + (size_t)r * count, src, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm));
+    }
+    MGX_TRY_RET(local_end(ctx, peers, k));  // nobody still reads my input: it may be overwritten in place now
+    hipLaunchKernelGGL(sum_ranks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->comm, (const double*)me.red,
+                       inout, count, ctx->nranks);
+    MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
 
@@ -96,22 +268,32 @@ int mgx_comm_init(mgx_ctx* ctx, const void* host_id_bytes, int rank, int nranks)
 }
 
 int mgx_local_group_create(int nranks, mgx_local_group** out) {
-    MGX_REQUIRE(out && nranks >= 1, MGX_ERR_INVALID, "bad arguments");
+    MGX_REQUIRE(out && nranks >= 1 && nranks <= 64, MGX_ERR_INVALID, "bad arguments (1 <= nranks <= 64)");
     mgx_local_group* g = new mgx_local_group();
     g->nranks = nranks;
-    g->post.resize(nranks);
-    if (pthread_barrier_init(&g->barrier, nullptr, (unsigned)nranks) != 0) {
-        delete g;
-        return mgx::fail(MGX_ERR_INVALID, "pthread_barrier_init failed");
-    }
+    g->rank.resize(nranks);
     *out = g;
     return MGX_OK;
 }
 
 int mgx_local_group_destroy(mgx_local_group* g) {
     if (!g) return MGX_OK;
-    pthread_barrier_destroy(&g->barrier);
+    for (auto& r : g->rank) {
+        for (int s = 0; s < mgx_local_group::SLOTS; s++) {
+            if (r.ready[s]) (void)hipEventDestroy(r.ready[s]);
+            if (r.done[s]) (void)hipEventDestroy(r.done[s]);
+        }
+        if (r.red) (void)hipFree(r.red);
+    }
     delete g;
+    return MGX_OK;
+}
+
+int mgx_local_group_set_test_hooks(mgx_local_group* g, int delay_us, int drop_waits) {
+    MGX_REQUIRE(g && delay_us >= 0 && delay_us <= 100000, MGX_ERR_INVALID, "bad arguments (0 <= delay_us <= 100000)");
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->delay_us = delay_us;
+    g->drop_waits = drop_waits ? 1 : 0;
     return MGX_OK;
 }
 
@@ -119,6 +301,14 @@ int mgx_comm_init_local(mgx_ctx* ctx, mgx_local_group* group, int rank) {
     MGX_REQUIRE(ctx && group, MGX_ERR_INVALID, "NULL argument");
     MGX_REQUIRE(rank >= 0 && rank < group->nranks, MGX_ERR_INVALID, "bad rank %d / %d", rank, group->nranks);
     MGX_REQUIRE(!ctx->rccl_comm && !ctx->local_group, MGX_ERR_INVALID, "communicator already initialised");
+    MGX_REQUIRE(!group->rank[rank].attached, MGX_ERR_INVALID, "rank %d is already attached", rank);
+    MGX_USE(ctx);
+    auto& me = group->rank[rank];
+    for (int s = 0; s < mgx_local_group::SLOTS; s++) {
+        MGX_HIP(hipEventCreateWithFlags(&me.ready[s], hipEventDisableTiming));
+        MGX_HIP(hipEventCreateWithFlags(&me.done[s], hipEventDisableTiming));
+    }
+    me.attached = true;
     ctx->local_group = group;
     ctx->rank = rank;
     ctx->nranks = group->nranks;
@@ -127,11 +317,13 @@ int mgx_comm_init_local(mgx_ctx* ctx, mgx_local_group* group, int rank) {
 
 int mgx_comm_destroy(mgx_ctx* ctx) {
     MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_USE(ctx);
     if (ctx->rccl_comm) {
         (void)hipStreamSynchronize(ctx->comm);
         ncclCommDestroy((ncclComm_t)ctx->rccl_comm);
         ctx->rccl_comm = nullptr;
     }
+    if (ctx->local_group) (void)hipStreamSynchronize(ctx->comm);
     ctx->local_group = nullptr;
     ctx->rank = 0;
     ctx->nranks = 1;
@@ -149,6 +341,7 @@ int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_to_lower, size_t count
                            size_t count_from_lower, const void* send_to_upper, size_t count_to_upper, void* recv_from_upper,
                            size_t count_from_upper, int elem_bytes) {
     MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_USE(ctx);
     MGX_REQUIRE(elem_bytes == 4 || elem_bytes == 8, MGX_ERR_INVALID, "elem_bytes = %d", elem_bytes);
     if (ctx->nranks == 1) return MGX_OK;
     const bool has_lo = ctx->rank > 0, has_up = ctx->rank < ctx->nranks - 1;
@@ -157,8 +350,9 @@ int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_to_lower, size_t count
     MGX_REQUIRE(!has_up || ((send_to_upper || !count_to_upper) && (recv_from_upper || !count_from_upper)), MGX_ERR_INVALID,
                 "upper-neighbour buffers are NULL");
     if (ctx->local_group)
-        return local_halo(ctx, send_to_lower, recv_from_lower, count_from_lower, send_to_upper, recv_from_upper,
-                          count_from_upper, elem_bytes);
+        return local_halo(ctx, count_to_lower ? send_to_lower : nullptr, recv_from_lower, recv_from_lower ? count_from_lower : 0,
+                          count_to_upper ? send_to_upper : nullptr, recv_from_upper, recv_from_upper ? count_from_upper : 0,
+                          elem_bytes);
     MGX_REQUIRE(ctx->rccl_comm, MGX_ERR_RCCL, "communicator not initialised");
     int st = order_after_compute(ctx);
     if (st) return st;
@@ -177,9 +371,12 @@ int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_to_lower, size_t count
     return MGX_OK;
 }
 
+// the compute stream waits for everything enqueued so far on the comm stream (both transports)
 int mgx_comm_wait(mgx_ctx* ctx) {
     MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
-    if (ctx->nranks == 1 || ctx->local_group) return MGX_OK;  // the local transport completes inside the call
+    MGX_USE(ctx);
+    if (ctx->nranks == 1) return MGX_OK;
+    if (ctx->local_group && ((mgx_local_group*)ctx->local_group)->drop_waits) return MGX_OK;  // fault injection (tests)
     MGX_HIP(hipEventRecord(ctx->ev_comm, ctx->comm));
     MGX_HIP(hipStreamWaitEvent(ctx->compute, ctx->ev_comm, 0));
     return MGX_OK;
@@ -187,23 +384,13 @@ int mgx_comm_wait(mgx_ctx* ctx) {
 
 int mgx_comm_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count, int elem_bytes) {
     MGX_REQUIRE(ctx && send && recv, MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     MGX_REQUIRE(elem_bytes == 4 || elem_bytes == 8, MGX_ERR_INVALID, "elem_bytes = %d", elem_bytes);
     if (ctx->nranks == 1) {
         if (send != recv) MGX_HIP(hipMemcpyAsync(recv, send, count * elem_bytes, hipMemcpyDeviceToDevice, ctx->compute));
         return MGX_OK;
     }
-    if (ctx->local_group) {
-        mgx_local_group* g = (mgx_local_group*)ctx->local_group;
-        MGX_HIP(hipStreamSynchronize(ctx->compute));
-        g->post[ctx->rank].gather = send;
-        pthread_barrier_wait(&g->barrier);
-        for (int r = 0; r < ctx->nranks; r++)
-            MGX_HIP(hipMemcpyAsync((char*)recv + (size_t)r * count * elem_bytes, g->post[r].gather, count * elem_bytes,
-                                   hipMemcpyDeviceToDevice, ctx->comm));
-        MGX_HIP(hipStreamSynchronize(ctx->comm));
-        pthread_barrier_wait(&g->barrier);
-        return MGX_OK;
-    }
+    if (ctx->local_group) return local_allgather(ctx, send, recv, count, elem_bytes);
     MGX_REQUIRE(ctx->rccl_comm, MGX_ERR_RCCL, "communicator not initialised");
     int st = order_after_compute(ctx);
     if (st) return st;
@@ -211,11 +398,12 @@ int mgx_comm_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count,
     return MGX_OK;
 }
 
-// Grouped ncclSend/ncclRecv of `count` doubles from this rank to itself on the comm stream, then an
-// all-gather and an all-reduce: exercises RCCL linkage, communicator and stream/event plumbing on a box
-// with a single GPU (nranks may be 1).  dev_src and dev_dst must not overlap.
+// Grouped ncclSend/ncclRecv of `count` doubles from this rank to itself on the comm stream: exercises RCCL
+// linkage, communicator and stream/event plumbing on a box with a single GPU (nranks may be 1).  dev_src and
+// dev_dst must not overlap.
 int mgx_comm_selftest(mgx_ctx* ctx, const double* dev_src, double* dev_dst, size_t count) {
     MGX_REQUIRE(ctx && dev_src && dev_dst && count, MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     MGX_REQUIRE(ctx->rccl_comm, MGX_ERR_RCCL, "RCCL communicator not initialised");
     int st = order_after_compute(ctx);
     if (st) return st;
@@ -230,10 +418,12 @@ int mgx_comm_selftest(mgx_ctx* ctx, const double* dev_src, double* dev_dst, size
     return MGX_OK;
 }
 
+// sum over the ranks, in place, of `count` doubles; every rank receives the same bits
 int mgx_comm_allreduce_sum_f64(mgx_ctx* ctx, double* dev_inout, size_t count) {
     MGX_REQUIRE(ctx && dev_inout, MGX_ERR_INVALID, "NULL argument");
-    if (ctx->nranks == 1) return MGX_OK;
-    MGX_REQUIRE(!ctx->local_group, MGX_ERR_INVALID, "allreduce is not implemented by the local test transport");
+    MGX_USE(ctx);
+    if (ctx->nranks == 1 || count == 0) return MGX_OK;
+    if (ctx->local_group) return local_allreduce(ctx, dev_inout, count);
     MGX_REQUIRE(ctx->rccl_comm, MGX_ERR_RCCL, "communicator not initialised");
     int st = order_after_compute(ctx);
     if (st) return st;

@@ -128,9 +128,9 @@ int mgx_ctx_destroy(mgx_ctx* ctx) {
 
 int mgx_ctx_sync(mgx_ctx* ctx) {
     MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_USE(ctx);
     MGX_HIP(hipStreamSynchronize(ctx->compute));
     MGX_HIP(hipStreamSynchronize(ctx->comm));
-    MGX_HIP(hipDeviceSynchronize());
     return MGX_OK;
 }
 
@@ -148,6 +148,7 @@ int mgx_ctx_stream(const mgx_ctx* ctx, void** hip_stream) {
 
 int mgx_malloc(mgx_ctx* ctx, size_t bytes, void** dptr) {
     MGX_REQUIRE(ctx && dptr, MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     *dptr = nullptr;
     if (bytes == 0) return MGX_OK;
     hipError_t e = hipMalloc(dptr, bytes);
@@ -160,6 +161,7 @@ int mgx_malloc(mgx_ctx* ctx, size_t bytes, void** dptr) {
 
 int mgx_free(mgx_ctx* ctx, void* dptr) {
     MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_USE(ctx);
     if (!dptr) return MGX_OK;
     MGX_HIP(hipStreamSynchronize(ctx->compute));
     MGX_HIP(hipStreamSynchronize(ctx->comm));
@@ -169,6 +171,7 @@ int mgx_free(mgx_ctx* ctx, void* dptr) {
 
 int mgx_memcpy_h2d(mgx_ctx* ctx, void* dst, const void* host_src, size_t bytes) {
     MGX_REQUIRE(ctx && (bytes == 0 || (dst && host_src)), MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     if (!bytes) return MGX_OK;
     MGX_HIP(hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, ctx->compute));
     MGX_HIP(hipStreamSynchronize(ctx->compute));
@@ -177,6 +180,7 @@ int mgx_memcpy_h2d(mgx_ctx* ctx, void* dst, const void* host_src, size_t bytes) 
 
 int mgx_memcpy_d2h(mgx_ctx* ctx, void* host_dst, const void* src, size_t bytes) {
     MGX_REQUIRE(ctx && (bytes == 0 || (host_dst && src)), MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     if (!bytes) return MGX_OK;
     MGX_HIP(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, ctx->compute));
     MGX_HIP(hipStreamSynchronize(ctx->compute));
@@ -185,6 +189,7 @@ int mgx_memcpy_d2h(mgx_ctx* ctx, void* host_dst, const void* src, size_t bytes) 
 
 int mgx_memcpy_d2d(mgx_ctx* ctx, void* dst, const void* src, size_t bytes) {
     MGX_REQUIRE(ctx && (bytes == 0 || (dst && src)), MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     if (!bytes) return MGX_OK;
     MGX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->compute));
     return MGX_OK;
@@ -192,17 +197,20 @@ int mgx_memcpy_d2d(mgx_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 int mgx_memset_zero(mgx_ctx* ctx, void* dst, size_t bytes) {
     MGX_REQUIRE(ctx && (bytes == 0 || dst), MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     return mgx::fill_zero(ctx, dst, bytes);
 }
 
 int mgx_graph_begin(mgx_ctx* ctx) {
     MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_USE(ctx);
     MGX_HIP(hipStreamBeginCapture(ctx->compute, hipStreamCaptureModeThreadLocal));
     return MGX_OK;
 }
 
 int mgx_graph_end(mgx_ctx* ctx, void** graph_exec) {
     MGX_REQUIRE(ctx && graph_exec, MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     *graph_exec = nullptr;
     hipGraph_t g = nullptr;
     MGX_HIP(hipStreamEndCapture(ctx->compute, &g));
@@ -216,18 +224,21 @@ int mgx_graph_end(mgx_ctx* ctx, void** graph_exec) {
 
 int mgx_graph_launch(mgx_ctx* ctx, void* graph_exec) {
     MGX_REQUIRE(ctx && graph_exec, MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     MGX_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->compute));
     return MGX_OK;
 }
 
 int mgx_graph_destroy(mgx_ctx* ctx, void* graph_exec) {
     MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_USE(ctx);
     if (graph_exec) MGX_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
     return MGX_OK;
 }
 
 int mgx_event_create(mgx_ctx* ctx, mgx_event** out) {
     MGX_REQUIRE(ctx && out, MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     mgx_event* e = new mgx_event();
     hipError_t r = hipEventCreate(&e->ev);
     if (r != hipSuccess) {
@@ -248,12 +259,14 @@ int mgx_event_destroy(mgx_ctx* ctx, mgx_event* ev) {
 
 int mgx_event_record(mgx_ctx* ctx, mgx_event* ev) {
     MGX_REQUIRE(ctx && ev, MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     MGX_HIP(hipEventRecord(ev->ev, ctx->compute));
     return MGX_OK;
 }
 
 int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float* ms) {
     MGX_REQUIRE(ctx && start && stop && ms, MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
     MGX_HIP(hipEventSynchronize(stop->ev));
     MGX_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
     return MGX_OK;

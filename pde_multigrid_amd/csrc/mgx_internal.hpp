@@ -32,6 +32,7 @@ struct mgx_ctx {
     void* local_group = nullptr;  // mgx_local_group* (in-process test transport)
     int rank = 0, nranks = 1;
     int num_cus = 256;
+    char last_relax_kernel[96] = "";  // name of the smoother kernel of the most recent colour pass (bench.py: roofline.kernel)
 };
 
 struct mgx_event {
@@ -58,6 +59,12 @@ int fill_zero(mgx_ctx* ctx, void* dst, size_t bytes);  // dst[0, bytes) := 0 on 
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+template <class real>
+inline void note_relax_kernel(mgx_ctx* ctx, const char* name, int a, int b, int c, bool fnt = false) {
+    snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "%s<%s,%d,%d,%d%s>", name, sizeof(real) == 8 ? "double" : "float",
+             a, b, c, fnt ? ",true" : "");
+}
+
 inline bool valid_size(int n) { return n >= 3 && ((n - 1) % 2 == 0); }
 
 }  // namespace mgx
@@ -75,6 +82,9 @@ inline bool valid_size(int n) { return n >= 3 && ((n - 1) % 2 == 0); }
         if (!(cond)) return mgx::fail(status, __VA_ARGS__); \
     } while (0)
 
+// every C-ABI entry that allocates, launches or synchronises makes the context's device current first: a context may be
+// used from a thread other than its creator (ctypes, thread-ranks), whose current device is otherwise 0
+#define MGX_USE(ctx) MGX_HIP(hipSetDevice((ctx)->device))
 #define MGX_LAUNCH_CHECK() MGX_HIP(hipGetLastError())
 #define MGX_TRY_RET(expr)            \
     do {                             \

@@ -277,6 +277,7 @@ template <class real>
 int relax2d(mgx_ctx* ctx, real* v, const real* f, const int n[2], const real h[2], const real a[2], const real A[4],
             int alfa, int ncycles) {
     MGX_REQUIRE(ctx && v && f && h && a && A, MGX_ERR_INVALID, "relax2d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n2(n, "relax2d");
     if (st) return st;
     MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "relax2d: ncycles = %d < 0", ncycles);
@@ -298,6 +299,7 @@ template <class real>
 int residual2d(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[2], const real h[2], const real a[2],
                const real A[4], int alfa) {
     MGX_REQUIRE(ctx && v && f && r && h && a && A, MGX_ERR_INVALID, "residual2d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n2(n, "residual2d");
     if (st) return st;
     hipLaunchKernelGGL((residual2d_kernel<real>), grd2(n[0], n[1]), blk2(), 0, ctx->compute, v, f, r, n[0], n[1],
@@ -309,6 +311,7 @@ int residual2d(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[
 template <class real>
 int restrict2d(mgx_ctx* ctx, const real* fine, const int fn[2], real* coarse, const int cn[2]) {
     MGX_REQUIRE(ctx && fine && coarse, MGX_ERR_INVALID, "restrict2d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n2(fn, "restrict2d");
     if (st) return st;
     st = check_coarse2(fn, cn, "restrict2d");
@@ -322,6 +325,7 @@ int restrict2d(mgx_ctx* ctx, const real* fine, const int fn[2], real* coarse, co
 template <class real, bool ADD>
 int interpolate2d(mgx_ctx* ctx, real* fine, const int fn[2], const real* coarse, const int cn[2]) {
     MGX_REQUIRE(ctx && fine && coarse, MGX_ERR_INVALID, "interpolate2d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n2(fn, "interpolate2d");
     if (st) return st;
     st = check_coarse2(fn, cn, "interpolate2d");
@@ -336,6 +340,7 @@ template <class real>
 int residual_restrict2d(mgx_ctx* ctx, const real* v, const real* f, const int n[2], const real h[2], const real a[2],
                         const real A[4], int alfa, real* coarse_f, const int cn[2]) {
     MGX_REQUIRE(ctx && v && f && h && a && A && coarse_f, MGX_ERR_INVALID, "residual_restrict2d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n2(n, "residual_restrict2d");
     if (st) return st;
     st = check_coarse2(n, cn, "residual_restrict2d");
@@ -349,6 +354,7 @@ int residual_restrict2d(mgx_ctx* ctx, const real* v, const real* f, const int n[
 template <class real>
 int correct2d(mgx_ctx* ctx, real* fine, const int fn[2], const real* err, const int en[2]) {
     MGX_REQUIRE(ctx && fine && err && en, MGX_ERR_INVALID, "apply_correction2d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n2(fn, "apply_correction2d");
     if (st) return st;
     for (int d = 0; d < 2; d++)  // N2/MultiGrid2D.cpp:351-352
@@ -362,6 +368,7 @@ int correct2d(mgx_ctx* ctx, real* fine, const int fn[2], const real* err, const 
 template <class real>
 int set2d(mgx_ctx* ctx, real* g, const int n[2], real value, int modify_boundaries) {
     MGX_REQUIRE(ctx && g, MGX_ERR_INVALID, "set2d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n2(n, "set2d");
     if (st) return st;
     const int lo = modify_boundaries ? 0 : 1;
@@ -378,6 +385,7 @@ template <class real>
 int jacobi2d(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[2], const real h[2], const real a[2], const real A[4],
              int alfa, real omega, int ncycles) {
     MGX_REQUIRE(ctx && v && tmp && f && h && a && A && v != tmp, MGX_ERR_INVALID, "jacobi2d: NULL or aliased argument");
+    MGX_USE(ctx);
     int st = check_n2(n, "jacobi2d");
     if (st) return st;
     MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "jacobi2d: ncycles = %d < 0", ncycles);
@@ -396,6 +404,7 @@ int jacobi2d(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[2], co
 template <class real>
 int mean_abs_error2d(mgx_ctx* ctx, const real* v, const int n[2], const real h[2], const real a[2], double* host_mean) {
     MGX_REQUIRE(ctx && v && h && a && host_mean, MGX_ERR_INVALID, "mean_abs_error2d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n2(n, "mean_abs_error2d");
     if (st) return st;
     void* ws = nullptr;

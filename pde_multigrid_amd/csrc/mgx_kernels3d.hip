@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(64 * TYW)
     }
 }
 
+#ifdef MGX_DIAGNOSTICS  // the A/B kernel without the software pipeline: measured slower, tools builds only
 // ------------------------------------------------------------------ relax, one colour, XSplit, edges through LDS
 // Same lane/row/plane assignment and the same per-point expression as relax3d_xs_kernel, but a workgroup is a
 // WX x WY arrangement of waves over an (x, y) tile of 64*WX pairs x R*WY rows, and the values a wave needs from
@@ -351,6 +352,8 @@ __global__ void __launch_bounds__(64 * WX * WY)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
+
+#endif  // MGX_DIAGNOSTICS
 
 // ------------------------------------------------------------------ relax, one colour, XSplit, LDS edges + prefetch
 // relax3d_xs_lds_kernel with the streaming loads software-pipelined one plane ahead, so that the per-plane barrier
@@ -1227,6 +1230,48 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const real* __restrict__ x, 
     if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
+// ------------------------------------------------------------------ sum of squares of the residual (no residual array)
+// One block per row (y, z) of the planes [zbeg, zend): the residual of its interior points is squared and summed in
+// double -- wavefront-wide shuffle reduction, the waves of the block combined in a fixed order -- into
+// partial[row]; residual_sumsq_final_kernel then adds the partials in a fixed order, so the result does not depend
+// on scheduling (same bits on every run and, after the all-reduce, on every rank).  An addition: the reference has no
+// norm.
+template <class real, class L, int MODE>
+__global__ void __launch_bounds__(256) residual_sumsq3d_kernel(const real* __restrict__ v, const real* __restrict__ f, int sx,
+                                                               int sy, int zbeg, real hx2, real hy2, real hz2,
+                                                               double* __restrict__ partial) {
+    const Geo<L, real> g(sx, sy);
+    const int y = 1 + blockIdx.x, z = zbeg + blockIdx.y;
+    const int H = g.H, P = g.P;
+    const size_t sxy = g.PL, row = g.row(y, z);
+    double acc = 0.0;
+    for (int x = 1 + threadIdx.x; x < sx - 1; x += 256) {
+        const size_t i = row + L::pos(x, H);
+        const real r = residual3d_point<real, MODE>(v[row + L::pos(x - 1, H)], v[row + L::pos(x + 1, H)], v[i - P], v[i + P],
+                                                    v[i - sxy], v[i + sxy], v[i], f[i], hx2, hy2, hz2);
+        acc += (double)r * (double)r;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ void __launch_bounds__(1024) residual_sumsq_final_kernel(const double* __restrict__ partial, size_t count,
+                                                                    double* __restrict__ out) {
+    __shared__ double s[1024];
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < count; i += 1024) acc += partial[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = s[0];
+}
+
 // =========================================================================== host side
 static inline dim3 blk() { return dim3(64, 4, 1); }
 static inline dim3 grd(int nx, int ny, int nz) { return dim3(ceil_div(nx, 64), ceil_div(ny, 4), nz); }
@@ -1263,6 +1308,7 @@ static void launch_xs(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int 
     const int M = (sx + 1) / 2;
     const int gx = ceil_div(M - 1, 64), gy = ceil_div(sy - 2, TYW * R), gz = ceil_div(zend - zbeg, zchunk);
     const unsigned nblocks = ctx->relax_xcd == 2 ? 8u * ((gx * gy + 7) / 8) * gz : (unsigned)gx * gy * gz;
+#ifdef MGX_DIAGNOSTICS
     if (TYW == 4 && R == 4 && ctx->relax_ablate) {  // diagnostics only
 #define MGX_ABL(A)                                                                                                   \
     case A:                                                                                                          \
@@ -1275,6 +1321,8 @@ static void launch_xs(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int 
         }
 #undef MGX_ABL
     }
+#endif
+    note_relax_kernel<real>(ctx, "relax3d_xs_kernel", TYW, R, 0);
     hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
                        (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
 }
@@ -1290,34 +1338,52 @@ static void launch_xs_rows(mgx_ctx* ctx, real* v, const real* f, int sx, int sy,
     }
 }
 
+// kind: 1 = relax3d_xs_pipe_kernel, 2 = the same with non-temporal loads of f (2 x 8 waves of 2 rows only),
+// 0 = relax3d_xs_lds_kernel (diagnostic builds)
 template <class real, int WX, int WY, int R>
 static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
-                          real hz2, int colour, int zchunk) {
+                          real hz2, int colour, int zchunk, int kind) {
     const int M = (sx + 1) / 2;
     const int gx = ceil_div(M - 1, 64 * WX), gy = ceil_div(sy - 2, WY * R), gz = ceil_div(zend - zbeg, zchunk);
-    if (ctx->relax_lds >= 3000 && R == 2 && WX * WY == 16)  // + 2000: f is loaded non-temporally (it is read once per pass)
-        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, WX, WY, (R == 2 && WX * WY == 16 ? R : 2), true>),
-                           dim3((unsigned)gx * gy * gz), dim3(64, WX * WY, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zbeg,
-                           zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd == 1 ? 1 : 0);
-    else if (ctx->relax_lds >= 1000)
-        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, WX, WY, R>), dim3((unsigned)gx * gy * gz), dim3(64, WX * WY, 1), 0,
-                           ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy,
-                           ctx->relax_xcd == 1 ? 1 : 0);
+    const dim3 grid((unsigned)gx * gy * gz), block(64, WX * WY, 1);
+    const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
+    note_relax_kernel<real>(ctx, kind ? "relax3d_xs_pipe_kernel" : "relax3d_xs_lds_kernel", WX, WY, R, kind == 2 && R == 2 && WX * WY == 16);
+    if (kind == 2 && R == 2 && WX * WY == 16)  // f is read once per pass: non-temporal loads
+        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, WX, WY, (R == 2 && WX * WY == 16 ? R : 2), true>), grid, block, 0,
+                           ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, xcd);
+#ifdef MGX_DIAGNOSTICS
+    else if (kind == 0)
+        hipLaunchKernelGGL((relax3d_xs_lds_kernel<real, WX, WY, R>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy,
+                           zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, xcd);
+#endif
     else
-        hipLaunchKernelGGL((relax3d_xs_lds_kernel<real, WX, WY, R>), dim3((unsigned)gx * gy * gz), dim3(64, WX * WY, 1), 0,
-                           ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy,
-                           ctx->relax_xcd == 1 ? 1 : 0);
+        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, WX, WY, R>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy,
+                           zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, xcd);
 }
 
-// LDS-exchange smoother: "relax3d.lds" = 100*WX + 10*WY + R picks the workgroup shape.  Returns false when the level is
-// too small for the shape (the caller falls back to relax3d_xs_kernel).
+// workgroup shapes 100*WX + 10*WY + R compiled into the library (diagnostic builds carry the whole sweep of round 1)
+#ifdef MGX_DIAGNOSTICS
+#define MGX_LDS_SHAPES(X)                                                                                          \
+    X(4, 2, 4) X(4, 4, 4) X(4, 4, 2) X(4, 2, 2) X(2, 4, 4) X(2, 2, 4) X(1, 4, 4) X(1, 8, 4) X(2, 8, 2) X(2, 4, 2) \
+    X(4, 2, 8) X(2, 2, 8) X(8, 2, 4) X(8, 1, 4) X(4, 1, 4) X(4, 1, 8)
+#else
+#define MGX_LDS_SHAPES(X) X(2, 8, 2) X(4, 4, 2) X(2, 4, 2) X(4, 2, 2) X(1, 8, 4) X(4, 2, 4)
+#endif
+static bool relax3d_lds_shape_known(int shape) {
+#define MGX_X(X, Y, RR) if (shape == 100 * X + 10 * Y + RR) return true;
+    MGX_LDS_SHAPES(MGX_X)
+#undef MGX_X
+    return false;
+}
+
+// LDS-exchange smoother: "relax3d.lds" = 1000 + 100*WX + 10*WY + R picks the workgroup shape (+ 2000: non-temporal f).
+// Returns false when the level is too small for the shape (the caller falls back to relax3d_xs_kernel).
 template <class real>
 static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
                                 real hz2, int colour) {
     const int M = (sx + 1) / 2;
     int zchunk = ctx->relax_zchunk;
     int code = ctx->relax_lds;
-    const int prev = ctx->relax_lds;
     if (code < 0) {
         // automatic (the default).  Measured on MI355X (tools/sweep_pipe.py, profiles/r01_sweep_pipe_*.txt): the
         // pipelined kernel with 2 x 8 waves of 2 rows wins from 257^3 up when the launch is ONE resident round of
@@ -1334,35 +1400,25 @@ static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, in
             const int nchunks = max(1, (target + tiles / 2) / tiles);
             zchunk = max(8, ceil_div(zend - zbeg, nchunks));
         }
-        ctx->relax_lds = code;  // launch_xs_lds picks the pipelined kernel from it
     }
-    code %= 1000;  // + 1000: the software-pipelined kernel (relax3d_xs_pipe_kernel)
+    const int kind = code >= 3000 ? 2 : (code >= 1000 ? 1 : 0);
+    code %= 1000;
     const int WX = code / 100, WY = (code / 10) % 10, R = code % 10;
-    if (M - 1 < 64 * WX || sy - 2 < WY * R) {
-        ctx->relax_lds = prev;
-        return false;
-    }
+    if (M - 1 < 64 * WX || sy - 2 < WY * R) return false;
     if (zchunk <= 0) {
         const long long tiles = (long long)ceil_div(M - 1, 64 * WX) * ceil_div(sy - 2, WY * R);
         zchunk = 16;
         while (zchunk > 2 && tiles * ceil_div(zend - zbeg, zchunk) * WX * WY < 32LL * ctx->num_cus) zchunk >>= 1;
     }
-    struct Restore {  // the launch below reads ctx->relax_lds; put the user's setting back on every path
-        mgx_ctx* c;
-        int v;
-        ~Restore() { c->relax_lds = v; }
-    } restore{ctx, prev};
-#define MGX_LDS(X, Y, RR)                                                                              \
-    case 100 * X + 10 * Y + RR:                                                                        \
-        launch_xs_lds<real, X, Y, RR>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk); \
+#define MGX_X(X, Y, RR)                                                                                  \
+    case 100 * X + 10 * Y + RR:                                                                          \
+        launch_xs_lds<real, X, Y, RR>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, kind); \
         return true;
     switch (code) {
-        MGX_LDS(4, 2, 4) MGX_LDS(4, 4, 4) MGX_LDS(4, 4, 2) MGX_LDS(4, 2, 2) MGX_LDS(2, 4, 4) MGX_LDS(2, 2, 4) MGX_LDS(1, 4, 4)
-        MGX_LDS(1, 8, 4) MGX_LDS(2, 8, 2) MGX_LDS(2, 4, 2) MGX_LDS(4, 2, 8) MGX_LDS(2, 2, 8) MGX_LDS(8, 2, 4) MGX_LDS(8, 1, 4)
-        MGX_LDS(4, 1, 4) MGX_LDS(4, 1, 8)
+        MGX_LDS_SHAPES(MGX_X)
         default: return false;
     }
-#undef MGX_LDS
+#undef MGX_X
 }
 
 // one colour pass over the local planes [zbeg, zend) of an x-split array with sx x sy rows
@@ -1418,6 +1474,7 @@ static int relax3d_xsplit(mgx_ctx* ctx, real* v, const real* f, const int n[3], 
 template <class real, class L>
 int relax3d(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles) {
     MGX_REQUIRE(ctx && v && f && h, MGX_ERR_INVALID, "relax3d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(n, "relax3d");
     if (st) return st;
     MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "relax3d: ncycles = %d < 0", ncycles);
@@ -1438,6 +1495,7 @@ int relax3d(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3
 template <class real, class L>
 int residual3d(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3], const real h[3], int mode) {
     MGX_REQUIRE(ctx && v && f && r && h, MGX_ERR_INVALID, "residual3d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(n, "residual3d");
     if (st) return st;
     MGX_REQUIRE(mode == MGX_RESIDUAL_REF_COMPAT || mode == MGX_RESIDUAL_CORRECT, MGX_ERR_INVALID, "residual3d: bad mode %d", mode);
@@ -1455,6 +1513,7 @@ int residual3d(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[
 template <class real, class L>
 int restrict3d(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse, const int cn[3]) {
     MGX_REQUIRE(ctx && fine && coarse, MGX_ERR_INVALID, "restrict3d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(fn, "restrict3d");
     if (st) return st;
     st = check_coarse3(fn, cn, "restrict3d");
@@ -1470,6 +1529,7 @@ template <class real>
 int restrict3d_slab(mgx_ctx* ctx, const real* fine, const int fn[3], int fzoff, real* coarse, const int cn[3], int czoff,
                     int pzbeg, int pzend) {
     MGX_REQUIRE(ctx && fine && coarse, MGX_ERR_INVALID, "restrict_slab: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(fn, "restrict_slab");
     if (st) return st;
     st = check_coarse3(fn, cn, "restrict_slab");
@@ -1486,6 +1546,7 @@ int restrict3d_slab(mgx_ctx* ctx, const real* fine, const int fn[3], int fzoff, 
 template <class real, class L, bool ADD>
 int interpolate3d(mgx_ctx* ctx, real* fine, const int fn[3], const real* coarse, const int cn[3]) {
     MGX_REQUIRE(ctx && fine && coarse, MGX_ERR_INVALID, "interpolate3d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(fn, "interpolate3d");
     if (st) return st;
     st = check_coarse3(fn, cn, "interpolate3d");
@@ -1503,6 +1564,7 @@ int interpolate3d(mgx_ctx* ctx, real* fine, const int fn[3], const real* coarse,
 template <class real, class L>
 int correct3d(mgx_ctx* ctx, real* fine, const int fn[3], const real* err, const int en[3]) {
     MGX_REQUIRE(ctx && fine && err && en, MGX_ERR_INVALID, "apply_correction3d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(fn, "apply_correction3d");
     if (st) return st;
     for (int d = 0; d < 3; d++)  // N3/MultiGrid3D.cpp:660-662
@@ -1516,6 +1578,7 @@ int correct3d(mgx_ctx* ctx, real* fine, const int fn[3], const real* err, const 
 template <class real, class L>
 int set3d(mgx_ctx* ctx, real* g, const int n[3], real value, int modify_boundaries) {
     MGX_REQUIRE(ctx && g, MGX_ERR_INVALID, "set3d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(n, "set3d");
     if (st) return st;
     const int lo = modify_boundaries ? 0 : 1;
@@ -1535,6 +1598,7 @@ int set3d(mgx_ctx* ctx, real* g, const int n[3], real value, int modify_boundari
 template <class real>
 int set3d_slab(mgx_ctx* ctx, real* g, int sx, int sy, int zbeg, int zend, real value) {
     MGX_REQUIRE(ctx && g, MGX_ERR_INVALID, "set_slab: NULL argument");
+    MGX_USE(ctx);
     MGX_REQUIRE(valid_size(sx) && valid_size(sy) && zbeg >= 0 && zend >= zbeg, MGX_ERR_SIZE, "set_slab: bad sizes");
     if (zend == zbeg) return MGX_OK;
     // set3d_kernel with lo = 1 writes the planes 1 .. sz-2 of the array it is given: hand it the planes zbeg-1 .. zend
@@ -1613,6 +1677,7 @@ template <class real, class L>
 int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[3], const real h[3], int mode,
                         real* coarse_f, const int cn[3], bool rim_is_zero = false) {
     MGX_REQUIRE(ctx && v && f && h && coarse_f, MGX_ERR_INVALID, "residual_restrict3d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(n, "residual_restrict3d");
     if (st) return st;
     st = check_coarse3(n, cn, "residual_restrict3d");
@@ -1644,6 +1709,7 @@ int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[
 template <class real, class L>
 int init_f3d(mgx_ctx* ctx, real* f, const int n[3], double c, const double* tx, const double* ty, const double* tz) {
     MGX_REQUIRE(ctx && f && tx && ty && tz, MGX_ERR_INVALID, "init_f3d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(n, "init_f3d");
     if (st) return st;
     const size_t cnt = (size_t)n[0] + n[1] + n[2];
@@ -1664,6 +1730,7 @@ int init_f3d(mgx_ctx* ctx, real* f, const int n[3], double c, const double* tx, 
 template <class real, class LS, class LD>
 int relayout3d(mgx_ctx* ctx, const real* src, real* dst, const int n[3]) {
     MGX_REQUIRE(ctx && src && dst, MGX_ERR_INVALID, "relayout3d: NULL argument");
+    MGX_USE(ctx);
     MGX_REQUIRE(src != dst, MGX_ERR_INVALID, "relayout3d: in-place conversion is not supported");
     int st = check_n3(n, "relayout3d");
     if (st) return st;
@@ -1679,6 +1746,7 @@ template <class real>
 int relax3d_colour_slab(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, const real h[3], int colour, int zbeg,
                         int zend, int zoff) {
     MGX_REQUIRE(ctx && v && f && h, MGX_ERR_INVALID, "relax_colour_slab: NULL argument");
+    MGX_USE(ctx);
     MGX_REQUIRE(valid_size(sx) && valid_size(sy), MGX_ERR_SIZE, "relax_colour_slab: sizes %d x %d are not 2^k+1", sx, sy);
     MGX_REQUIRE((colour == 0 || colour == 1) && zbeg >= 1 && zend >= zbeg && zoff >= 0, MGX_ERR_INVALID,
                 "relax_colour_slab: bad colour / plane range");
@@ -1692,6 +1760,7 @@ template <class real>
 int residual_restrict3d_slab(mgx_ctx* ctx, const real* v, const real* f, const int n[3], int fzoff, const real h[3],
                              int mode, real* coarse_f, const int cn[3], int czoff, int pzbeg, int pzend) {
     MGX_REQUIRE(ctx && v && f && h && coarse_f, MGX_ERR_INVALID, "residual_restrict_slab: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(n, "residual_restrict_slab");
     if (st) return st;
     st = check_coarse3(n, cn, "residual_restrict_slab");
@@ -1722,10 +1791,41 @@ int residual_restrict3d_slab(mgx_ctx* ctx, const real* v, const real* f, const i
     return MGX_OK;
 }
 
+// sum over the (x, y)-interior points of the local planes [zbeg, zend) of the squared residual -> *dev_out (a device
+// double), asynchronously on the compute stream; the planes zbeg-1 and zend must hold valid v (ghosts / boundary)
+template <class real>
+int residual_sumsq3d_slab(mgx_ctx* ctx, const real* v, const real* f, int sx, int sy, const real h[3], int mode, int zbeg,
+                          int zend, double* dev_out) {
+    MGX_REQUIRE(ctx && v && f && h && dev_out, MGX_ERR_INVALID, "residual_sumsq_slab: NULL argument");
+    MGX_USE(ctx);
+    MGX_REQUIRE(valid_size(sx) && valid_size(sy), MGX_ERR_SIZE, "residual_sumsq_slab: sizes %d x %d are not 2^k+1", sx, sy);
+    MGX_REQUIRE(zbeg >= 1 && zend >= zbeg, MGX_ERR_INVALID, "residual_sumsq_slab: bad plane range");
+    MGX_REQUIRE(mode == MGX_RESIDUAL_REF_COMPAT || mode == MGX_RESIDUAL_CORRECT, MGX_ERR_INVALID, "bad residual mode %d", mode);
+    if (zend == zbeg) {
+        MGX_HIP(hipMemsetAsync(dev_out, 0, sizeof(double), ctx->compute));
+        return MGX_OK;
+    }
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    const size_t rows = (size_t)(sy - 2) * (size_t)(zend - zbeg);
+    void* ws = nullptr;
+    MGX_TRY_RET(workspace(ctx, rows * sizeof(double), &ws));
+    const dim3 g(sy - 2, zend - zbeg);
+    if (mode == MGX_RESIDUAL_REF_COMPAT)
+        hipLaunchKernelGGL((residual_sumsq3d_kernel<real, XSplit, 0>), g, dim3(256), 0, ctx->compute, v, f, sx, sy, zbeg, hx2, hy2,
+                           hz2, (double*)ws);
+    else
+        hipLaunchKernelGGL((residual_sumsq3d_kernel<real, XSplit, 1>), g, dim3(256), 0, ctx->compute, v, f, sx, sy, zbeg, hx2, hy2,
+                           hz2, (double*)ws);
+    hipLaunchKernelGGL(residual_sumsq_final_kernel, dim3(1), dim3(1024), 0, ctx->compute, (const double*)ws, rows, dev_out);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
 template <class real>
 int interpolate_correct3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff, const real* coarse_v, const int cn[3],
                                int czoff, int pzbeg, int pzend, int colour, bool add = true) {
     MGX_REQUIRE(ctx && v && coarse_v, MGX_ERR_INVALID, "interpolate_correct_slab: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(n, "interpolate_correct_slab");
     if (st) return st;
     st = check_coarse3(n, cn, "interpolate_correct_slab");
@@ -1757,6 +1857,7 @@ int interpolate_correct3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff,
 template <class real, class L>
 int jacobi3d(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[3], const real h[3], real omega, int ncycles) {
     MGX_REQUIRE(ctx && v && tmp && f && h, MGX_ERR_INVALID, "jacobi3d: NULL argument");
+    MGX_USE(ctx);
     MGX_REQUIRE(v != tmp, MGX_ERR_INVALID, "jacobi3d: v and tmp must differ");
     int st = check_n3(n, "jacobi3d");
     if (st) return st;
@@ -1780,6 +1881,7 @@ template <class real, class L>
 int diff_stats3d(mgx_ctx* ctx, const real* v, const int n[3], const double* tx, const double* ty, const double* tz,
                  double host_out[4]) {
     MGX_REQUIRE(ctx && v && tx && ty && tz && host_out, MGX_ERR_INVALID, "diff_stats3d: NULL argument");
+    MGX_USE(ctx);
     int st = check_n3(n, "diff_stats3d");
     if (st) return st;
     const size_t cnt = (size_t)n[0] + n[1] + n[2];
@@ -1802,6 +1904,7 @@ int diff_stats3d(mgx_ctx* ctx, const real* v, const int n[3], const double* tx, 
 template <class real>
 int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
     MGX_REQUIRE(ctx && (x || !count) && host_sumsq, MGX_ERR_INVALID, "norm2: NULL argument");
+    MGX_USE(ctx);
     void* ws = nullptr;
     int st = workspace(ctx, sizeof(double), &ws);
     if (st) return st;
@@ -1880,6 +1983,10 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
         return mgx::residual_restrict3d_slab<real>(ctx, v, f, n, fzoff, h, mode, coarse_f, cn, czoff, pzbeg,     \
                                                    pzend);                                                       \
     }                                                                                                            \
+    int mgx3dxs_residual_sumsq_slab_##SFX(mgx_ctx* ctx, const real* v, const real* f, int sx, int sy,            \
+                                          const real h[3], int mode, int zbeg, int zend, double* dev_out) {      \
+        return mgx::residual_sumsq3d_slab<real>(ctx, v, f, sx, sy, h, mode, zbeg, zend, dev_out);                \
+    }                                                                                                            \
     int mgx3dxs_interpolate_correct_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff,                 \
                                                const real* coarse_v, const int cn[3], int czoff, int pzbeg,      \
                                                int pzend) {                                                      \
@@ -1927,15 +2034,22 @@ MGX_DEFINE_OPS3D(mgx3dxs_, mgx::XSplit, f64, double)
 MGX_DEFINE_MISC3D(f32, float)
 MGX_DEFINE_MISC3D(f64, double)
 
+const char* mgx_ctx_last_relax_kernel(const mgx_ctx* ctx) { return ctx ? ctx->last_relax_kernel : ""; }
+
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     MGX_REQUIRE(ctx && name, MGX_ERR_INVALID, "set_param: NULL argument");
+    MGX_USE(ctx);
     if (!strcmp(name, "relax3d.ty")) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.ty (waves per block) must be 1, 2, 4 or 8");
         ctx->relax_ty = value;
     } else if (!strcmp(name, "relax3d.small")) {
         ctx->relax_small = value ? 1 : 0;  // one-workgroup LDS kernel for levels <= 17^3
     } else if (!strcmp(name, "relax3d.ablate")) {
-        ctx->relax_ablate = value;  // diagnostics: non-zero gives WRONG results (see relax3d_xs_kernel)
+#ifdef MGX_DIAGNOSTICS
+        ctx->relax_ablate = value;  // diagnostic builds only: non-zero gives WRONG results (see relax3d_xs_kernel)
+#else
+        return mgx::fail(MGX_ERR_INVALID, "set_param: 'relax3d.ablate' exists only in diagnostic builds (make diag)");
+#endif
     } else if (!strcmp(name, "relax3d.wave_planes")) {
         ctx->relax_wave_planes = value;  // < 0 automatic, 0 off (whole-grid passes), > 0 planes per slab
     } else if (!strcmp(name, "relax3d.rows")) {
@@ -1945,14 +2059,23 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "relax3d.xcd must be 0, 1 or 2");
         ctx->relax_xcd = value;
     } else if (!strcmp(name, "relax3d.lds")) {
-        ctx->relax_lds = value;  // -1 = automatic (default), 0 = relax3d_xs_kernel, 100*WX + 10*WY + R = relax3d_xs_lds_kernel<WX, WY, R>,
-                                 // 1000 + that = relax3d_xs_pipe_kernel<WX, WY, R>
+        // -1 = automatic (default), 0 = relax3d_xs_kernel, 1000 + 100*WX + 10*WY + R = relax3d_xs_pipe_kernel<WX, WY, R>,
+        // 3282 = the 2 x 8 x 2 shape with non-temporal loads of f; below 1000 (no software pipeline): diagnostic builds
+        bool ok = value == -1 || value == 0 || value == 3282 || (value >= 1000 && value < 2000 && mgx::relax3d_lds_shape_known(value - 1000));
+#ifdef MGX_DIAGNOSTICS
+        ok = ok || (value > 0 && value < 1000 && mgx::relax3d_lds_shape_known(value)) || (value >= 3000 && mgx::relax3d_lds_shape_known(value - 3000));
+#endif
+        MGX_REQUIRE(ok, MGX_ERR_INVALID, "relax3d.lds = %d is not a kernel shape of this build", value);
+        ctx->relax_lds = value;
     } else if (!strcmp(name, "residual_restrict3d.cr")) {
-        ctx->rr_cr = value;   // coarse rows per lane of the streaming kernel: 1 or 2 (0 = by level size)
+        MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "residual_restrict3d.cr must be 0 (by level size), 1 or 2");
+        ctx->rr_cr = value;   // coarse rows per lane of the streaming kernel
     } else if (!strcmp(name, "residual_restrict3d.tyw")) {
-        ctx->rr_tyw = value;  // waves per block: 2, 4 or 8
+        MGX_REQUIRE(value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "residual_restrict3d.tyw (waves per block) must be 2, 4 or 8");
+        ctx->rr_tyw = value;
     } else if (!strcmp(name, "residual_restrict3d.stream")) {
-        ctx->rr_stream = value < 0 || value > 3 ? 3 : value;  // 0 = LDS rolling-window kernel, 1 = streaming shuffle kernel,
+        MGX_REQUIRE(value >= 0 && value <= 3, MGX_ERR_INVALID, "residual_restrict3d.stream must be 0 ... 3");
+        ctx->rr_stream = value;  // 0 = LDS rolling-window kernel, 1 = streaming shuffle kernel,
                                                               // 2 = pipelined with halos through LDS (x-split), 3 = 2 on large levels, else 1 (default)
     } else if (!strcmp(name, "residual_restrict3d.pzchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "residual_restrict3d.pzchunk must be >= 0 (0 = automatic)");

@@ -1,5 +1,5 @@
 // mgx_kernels3d.hpp -- per-point expressions of the 3D operators (device inline), shared by
-// the natural-layout kernels (mgx_kernels3d.hip) and the red-black planar ones (mgx_rb3d.hip).
+// the kernels of both array layouts (natural and x-split) in mgx_kernels3d.hip.
 //
 // These are the ONLY places where the arithmetic of the reference is restated on the device;
 // each keeps the reference's association order so that results are bit-identical

@@ -81,6 +81,9 @@ class Context:
     def free(self, p):
         check(lib.mgx_free(self._h, p))
 
+    def last_relax_kernel(self):
+        return lib.mgx_ctx_last_relax_kernel(self._h).decode()
+
     def set_param(self, name, value):
         check(lib.mgx_ctx_set_param(self._h, name.encode(), C.c_int(int(value))))
 
@@ -663,6 +666,11 @@ class LocalGroup:
     def attach(self, ctx, rank):
         check(lib.mgx_comm_init_local(ctx._h, self._g, int(rank)))
 
+    def set_test_hooks(self, delay_us=0, drop_waits=False):
+        """delay_us: every transfer starts that late on the receiving comm stream; drop_waits: mgx_comm_wait becomes a
+        no-op (fault injection -- results must then be WRONG, which is what the negative test checks)"""
+        check(lib.mgx_local_group_set_test_hooks(self._g, int(delay_us), int(bool(drop_waits))))
+
     def close(self):
         if self._g:
             lib.mgx_local_group_destroy(self._g)
@@ -677,7 +685,8 @@ def _dist_struct(ct):
     class DistMultiGrid3D(C.Structure):
         _fields_ = [("slabs", C.POINTER(C.POINTER(Slab3D))), ("numDist", C.c_int), ("numGrids", C.c_int), ("maxGrids", C.c_int),
                     ("tail", C.c_void_p), ("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
-                    ("residual_mode", C.c_int), ("d_share", C.c_void_p), ("d_bplane", C.c_void_p)]
+                    ("residual_mode", C.c_int), ("d_share", C.c_void_p), ("d_bplane", C.c_void_p), ("d_norm", C.c_void_p),
+                    ("norm_count", C.c_int)]
 
     return Slab3D, DistMultiGrid3D
 
@@ -722,6 +731,21 @@ class DistMultiGrid3D(_MGBase):
     def zero_v(self, gridID=0):
         self._call("zero_v", C.c_int(gridID))
 
+    def ResidualNorm(self, gridID=0):
+        """l2 norm of the residual over the whole grid (slab sums + all-reduce); the same value on every rank"""
+        out = C.c_double()
+        self._call("ResidualNorm", C.c_int(gridID), C.byref(out))
+        return float(out.value)
+
+    def ResidualNormRecord(self, gridID=0):
+        self._call("ResidualNormRecord", C.c_int(gridID))
+
+    def ResidualNormHistory(self):
+        buf = (C.c_double * 255)()
+        n = C.c_int()
+        self._call("ResidualNormHistory", buf, C.c_int(255), C.byref(n))
+        return [float(buf[i]) for i in range(n.value)]
+
     def slab(self, gridID=0):
         return self._mg.contents.slabs[gridID].contents
 
@@ -742,6 +766,17 @@ class DistMultiGrid3D(_MGBase):
     def upload_f(self, gridID, full):
         full = np.ascontiguousarray(full, self.dtype)
         self._call("upload_f", C.c_int(gridID), full.ctypes.data_as(C.c_void_p))
+
+    def download_owned(self, gridID=0):
+        """this rank's owned planes [plan.zlo, plan.zhi) of level gridID as an array of its own (reference layout)"""
+        p = self.plan(gridID)
+        g = self.slab(gridID)
+        sx, sy = g.sizeXYZ[0], g.sizeXYZ[1]
+        out = np.empty((p.zhi - p.zlo, sy, sx), self.dtype)
+        # the C entry addresses planes of a whole-grid host array: hand it the address plane 0 would have
+        base = out.ctypes.data - p.zlo * sx * sy * self.dtype.itemsize
+        self._call("download_v", C.c_int(gridID), C.c_void_p(base))
+        return out
 
     def download_v_into(self, gridID, full):
         """writes this rank's owned planes into `full` (a whole-grid array in the reference layout)"""

@@ -1,9 +1,13 @@
 """GPU suite: the slab-decomposed V-cycle driver (csrc/host/mg_dist3d.inc) with the real HIP kernels.
 The gpurun box has one GPU, so the ranks are host threads of this process, one context each on the same
-device, joined by the in-process test transport (mgx_comm_init_local: device-to-device copies + pthread
-barrier instead of RCCL send/recv).  Everything else -- slab plan, ghost handling, z-range kernels,
-agglomeration through the replicated tail -- is the production code.  Bar: bit-identical to the
-single-GPU hierarchy and to the oracle."""
+device, joined by the in-process test transport (mgx_comm_init_local).  Like RCCL it is asynchronous: an
+exchange only enqueues device-to-device copies on the comm stream, ordered against the neighbours by
+cross-context events, and the compute stream sees the ghosts only through mgx_comm_wait -- so the overlap
+schedule's event ordering is what is being tested, not just its arithmetic.  Every test runs with the
+transport's delay hook on (each transfer starts DELAY_US late on the receiving comm stream): a missing or
+misplaced wait then reads stale ghosts for certain, and test_dist_missing_wait_is_detected proves it.
+Everything else -- slab plan, ghost handling, z-range kernels, agglomeration through the replicated tail --
+is the production code.  Bar: bit-identical to the single-GPU hierarchy and to the oracle."""
 import threading
 
 import numpy as np
@@ -15,11 +19,14 @@ from conftest import bits_equal
 
 pytestmark = pytest.mark.gpu
 R3 = [0, 1, 0, 1, 0, 1]
+DELAY_US = 300  # a colour pass of these grids takes 5-50 us: every transfer arrives long after the next kernel could start
 
 
-def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COMPAT, v0=None, f0=None, nlevels=0, fmg=0):
+def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COMPAT, v0=None, f0=None, nlevels=0, fmg=0,
+              delay_us=DELAY_US, drop_waits=False, extra=None, join_timeout=100):
     ctxs = [P.Context(0) for _ in range(nranks)]
     group = P.LocalGroup(nranks)
+    group.set_test_hooks(delay_us, drop_waits)
     for r, c in enumerate(ctxs):
         group.attach(c, r)
     full = np.full(tuple(reversed(n3)), np.nan, dtype)
@@ -37,6 +44,8 @@ def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COM
                 mg.FullMultiGridVCycle(0, fmg, v1, v2)
             for _ in range(cycles):
                 mg.VCycle(0, v1, v2)
+            if extra is not None:
+                info[("extra", r)] = extra(mg)
             mg.download_v_into(0, full)
             mg.close()
         except Exception as e:  # noqa: BLE001
@@ -46,7 +55,7 @@ def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COM
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=100)
+        t.join(timeout=join_timeout)
     alive = [t for t in threads if t.is_alive()]
     assert not errors, errors
     assert not alive, "a rank is stuck in an exchange (another rank failed or the schedule is unbalanced)"
@@ -161,3 +170,105 @@ def test_rccl_plumbing_single_rank():
     ctx.free(src)
     ctx.free(dst)
     ctx.close()
+
+
+@pytest.mark.timeout(200)
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_dist_missing_wait_is_detected(nranks):
+    """NEGATIVE test of the harness: with mgx_comm_wait turned into a no-op (fault injection of the test transport) the
+    compute stream runs ahead of the ghost transfers and the result must differ from the oracle; with the waits in
+    place the same configuration is bit-identical.  Without this, a missing wait in the overlap schedule could pass
+    every test (the transfers of small grids would usually win the race by luck)."""
+    n3 = [65, 33, 65]
+    rng = np.random.default_rng(5)
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    v0 = rng.uniform(-1, 1, O.shape(n3))
+    f0 = rng.uniform(-1, 1, O.shape(n3))
+    want = O.cycle3d(n3, rg, mode=0, v1=2, v2=2, reps=1, v=v0, f=f0, dtype=np.float64)
+    good, _ = run_ranks(nranks, n3, rg, np.float64, 2, 2, 1, 4, v0=v0, f0=f0, delay_us=1000)
+    assert bits_equal(good, want)
+    bad, _ = run_ranks(nranks, n3, rg, np.float64, 2, 2, 1, 4, v0=v0, f0=f0, delay_us=1000, drop_waits=True)
+    assert not np.isnan(bad).any()
+    assert not bits_equal(bad, want), "the dropped waits went unnoticed: the transport is not exercising the event ordering"
+    good0, _ = run_ranks(nranks, n3, rg, np.float64, 2, 2, 1, 4, v0=v0, f0=f0, delay_us=0)  # and without the delay
+    assert bits_equal(good0, want)
+
+
+@pytest.mark.timeout(200)
+@pytest.mark.parametrize("nranks", [1, 2, 4])
+@pytest.mark.parametrize("mode", [P.REF_COMPAT, P.CORRECT])
+def test_dist_residual_norm_allreduce(nranks, mode):
+    """mgDistMultiGrid3D_ResidualNorm: slab sums of the squared residual (device reduction in a fixed order) + one
+    all-reduce of one double; every rank gets the same bits.  ADDITION without a reference: parity
+    unpinned, checked against numpy on the oracle's residual of the oracle's v (relative 1e-12)."""
+    n3 = [65, 33, 65]
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(9)
+    v0 = rng.uniform(-1, 1, O.shape(n3))
+    f0 = rng.uniform(-1, 1, O.shape(n3))
+
+    def extra(mg):
+        a = mg.ResidualNorm(0)
+        mg.ResidualNormRecord(0)
+        mg.VCycle(0, 1, 1)
+        mg.ResidualNormRecord(0)
+        return a, mg.ResidualNorm(0), mg.ResidualNormHistory()
+
+    _, info = run_ranks(nranks, n3, rg, np.float64, 2, 2, 1, 4, mode=mode, v0=v0, f0=f0, extra=extra)
+    v1 = O.cycle3d(n3, rg, mode=0, v1=2, v2=2, reps=1, v=v0, f=f0, residual_mode=mode, dtype=np.float64)
+    v2 = O.cycle3d(n3, rg, mode=0, v1=1, v2=1, reps=1, v=v1, f=f0, residual_mode=mode, dtype=np.float64)
+    want = [float(np.sqrt(np.sum(O.residual3d(n3, rg, v, f0, mode, dtype=np.float64) ** 2))) for v in (v1, v2)]
+    got = [info[("extra", r)] for r in range(nranks)]
+    for g in got[1:]:
+        assert g == got[0], "ranks disagree on the all-reduced norm"
+    a, b, hist = got[0]
+    assert abs(a - want[0]) <= 1e-12 * want[0] and abs(b - want[1]) <= 1e-12 * want[1]
+    assert hist == [a, b]
+
+
+@pytest.mark.timeout(100)
+def test_local_transport_allreduce_and_allgather_bits():
+    """the test transport's collectives: all-reduce = sum in rank order on every rank (same bits), all-gather in rank order"""
+    import ctypes as C
+    nranks, count = 4, 1000
+    ctxs = [P.Context(0) for _ in range(nranks)]
+    group = P.LocalGroup(nranks)
+    group.set_test_hooks(DELAY_US, False)
+    for r, c in enumerate(ctxs):
+        group.attach(c, r)
+    rng = np.random.default_rng(1)
+    data = [rng.uniform(-1, 1, count) * 10.0 ** rng.integers(-8, 8, count) for _ in range(nranks)]
+    out, errors = {}, []
+
+    def worker(r):
+        try:
+            c = ctxs[r]
+            x = c.to_device(data[r])
+            g = c.malloc(nranks * count * 8)
+            P.check(P.lib.mgx_comm_allgather(c._h, x, g, C.c_size_t(count), C.c_int(8)))
+            P.check(P.lib.mgx_comm_wait(c._h))
+            gathered = c.to_host(g, (nranks, count), np.float64)
+            P.check(P.lib.mgx_comm_allreduce_sum_f64(c._h, x, C.c_size_t(count)))
+            P.check(P.lib.mgx_comm_wait(c._h))
+            out[r] = (gathered, c.to_host(x, (count,), np.float64))
+            c.free(x)
+            c.free(g)
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    assert not errors, errors
+    assert not [t for t in threads if t.is_alive()]
+    want = data[0].copy()
+    for r in range(1, nranks):
+        want = want + data[r]
+    for r in range(nranks):
+        assert bits_equal(out[r][0], np.stack(data))
+        assert bits_equal(out[r][1], want)
+    for c in ctxs:
+        c.close()
+    group.close()

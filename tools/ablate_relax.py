@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Ablation of the x-split smoother kernel (diagnostic builds, WRONG results): which resource bounds it?
     python tools/ablate_relax.py [--n 513]
 mask bits: 1 = no f load, 2 = no store, 4 = no side/edge loads (only the streaming U load), 8 = no division,
@@ -9,7 +9,10 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the ablation variants live in the diagnostic twin only: make -C pde_multigrid_amd/csrc diag
+os.environ.setdefault("MGX_LIB_PATH", os.path.join(ROOT, "pde_multigrid_amd", "lib", "libmgx_diag.so"))
 import pde_multigrid_amd as P  # noqa: E402
 
 ap = argparse.ArgumentParser()

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Timing of the secondary configurations (BASELINE.json configs[1], [2]; fp32; FMG) on one MI355X."""
 import os
 import sys

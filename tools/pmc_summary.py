@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Summarise rocprofv3 CSV output (kernel-trace --stats and --pmc passes) into small text/JSON
 files that are committed under profiles/.
 

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Run only the finest-level smoother (for rocprofv3 --pmc passes on one parameter set).
     python3 tools/relax_only.py [--n=513] [name=value,...]"""
 import os

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Run-to-run and kernel-to-kernel reproducibility at the bench size: 30 V(2,2) cycles at 513^3 fp64, twice with the
 default kernels and once with the previous generation (relax3d.lds = 0, residual_restrict3d.stream = 1); the three
 results must be bit-identical (a race in an in-place update would show up here long before it does in a short test)."""

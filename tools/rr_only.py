@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Run only residual+restrict + interpolate+correct of the finest level (for rocprofv3 --pmc passes).
     python3 tools/rr_only.py [--n=513] [name=value,...]"""
 import os

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """One GPU's share of the 1025^3 problem as a stand-alone grid: 1025 x 1025 x (1024/N + 1) points, V(2,2) cycle time
 (no exchanges) against 1/N of the full 1025^3 cycle.  A sanity check of the kernels on thin slabs."""
 import os

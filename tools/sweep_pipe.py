@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Sweep workgroup shape and z-chunk count of relax3d_xs_pipe_kernel ("relax3d.lds" = 1000 + 100*WX + 10*WY + R).
     python tools/sweep_pipe.py --n=513 [--dtype=f32] [--planes=NZ]   (NZ: slab height, default n)"""
 import os

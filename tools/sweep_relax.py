@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Tuning sweep of the 3D smoother on one MI355X: interleaved rounds in ONE process
 (cdna_hip_programming.md rule 24), HIP-event timing on the compute stream.
 

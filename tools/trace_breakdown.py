@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Per-kernel / per-grid-size breakdown of a rocprofv3 --kernel-trace CSV, plus GPU idle time between kernels.
     python tools/trace_breakdown.py <rocprof_out_dir> [--skip N]   (skip the first N dispatches: set-up, warm-up)"""
 import collections

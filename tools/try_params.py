@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """A/B a set of context parameters on the smoother (interleaved rounds, one process).
     python tools/try_params.py "relax3d.nt=0" "relax3d.nt=1" "relax3d.nt=2,relax3d.zchunk=8" ... [--n 513]"""
 import os
