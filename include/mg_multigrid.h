@@ -191,7 +191,10 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         int sizeA;                                                                                       \
         int alfa;                                                                                        \
         mgx_ctx* ctx;                                                                                    \
-        int fuse;                                                                                        \
+        int fuse; /* 2 (default): VCycle on the cache-resident kernels (one launch per level and direction, */ \
+                  /* one for all levels <= 65^2); 1: CalculateResidual+Restrict and Interpolate+             */ \
+                  /* ApplyCorrection fused, one launch per colour pass; 0: one launch per reference call.    */ \
+                  /* Results are bit-identical.                                                              */ \
         int smoother; /* 0 = red-black Gauss-Seidel (the reference), 1 = weighted Jacobi (addition) */   \
         real omega;                                                                                      \
         int use_graph; /* as in mgMultiGrid3D: the 1025^2 cycle is launch-bound */                       \

@@ -253,6 +253,31 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                                       real* coarse_f, const int cn[2]);                                 \
     int mgx2d_interpolate_correct_##SFX(mgx_ctx* ctx, real* v, const int n[2], const real* coarse_v,    \
                                         const int cn[2]);                                               \
+    /* Cache-resident cycle kernels of the 2D path (the 1025^2 hierarchy never leaves L2 / Infinity     */ \
+    /* Cache: the cycle is bound by launches, not HBM).  The upwind stencil {C, x+1, y+1} is one-sided, */ \
+    /* so a workgroup that holds a tile plus a halo on the +x / +y side in LDS runs all colour passes   */ \
+    /* of a Relax call on it, together with the operator next to it in VCycle -- bit-identical to the   */ \
+    /* separate calls, OUT OF PLACE (tiles overlap: v_in != v_out), 0 <= ncycles <= 4:                  */ \
+    /*   relax_residual_restrict: v_out = Relax(v_in, ncycles); coarse_f = Restrict(CalculateResidual(  */ \
+    /*     v_out)) unless coarse_f is NULL (N2/MultiGrid2D.cpp:317-323); v_zero != 0: v_in is taken as  */ \
+    /*     all zeros without being read (the coarse error after setToValue(v, 0, true), :326)           */ \
+    /*   interpolate_correct_relax: v_out = Relax(v_in + Interpolate(coarse_v), ncycles)   (:333-338)   */ \
+    /*   vcycle_tail: the whole VCycle(v1, v2) over levels[0 .. nlev) -- each at most 65^2, n and h     */ \
+    /*     flattened {x0, y0, x1, y1, ...}, v / f HOST arrays of device pointers -- in ONE workgroup     */ \
+    /*     with every level in LDS (:314-340); leaves v of all levels and f of levels 1.. as the        */ \
+    /*     launch-per-operator cycle does.  _fits: do the levels fit into LDS (1) or not (0)            */ \
+    int mgx2d_relax_residual_restrict_##SFX(mgx_ctx* ctx, const real* v_in, real* v_out, const real* f, \
+                                            const int n[2], const real h[2], const real a[2],           \
+                                            const real A[4], int alfa, int ncycles, int v_zero,         \
+                                            real* coarse_f, const int cn[2]);                           \
+    int mgx2d_interpolate_correct_relax_##SFX(mgx_ctx* ctx, const real* v_in, real* v_out,              \
+                                              const real* f, const int n[2], const real h[2],           \
+                                              const real a[2], const real A[4], int alfa,               \
+                                              const real* coarse_v, const int cn[2], int ncycles);      \
+    int mgx2d_vcycle_tail_##SFX(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const int* n,   \
+                                const real* h, const real a[2], const real A[4], int alfa, int v1,      \
+                                int v2, int top_zero);                                                  \
+    int mgx2d_vcycle_tail_fits_##SFX(int nlev, const int* n);                                           \
     int mgx2d_interpolate_##SFX(mgx_ctx* ctx, real* fine, const int fn[2], const real* coarse,          \
                                 const int cn[2]);                                                       \
     int mgx2d_apply_correction_##SFX(mgx_ctx* ctx, real* fine, const int fn[2], const real* err,        \

@@ -26,41 +26,46 @@ OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "known_answers_f64.
 R3 = [0, 1, 0, 1, 0, 1]
 
 
-def checksum64(a):
-    """(sum w_i, sum w_i * (2 i + 1)) mod 2^64 over the 64-bit words of `a` in memory order"""
-    w = np.ascontiguousarray(a).reshape(-1).view(np.uint64)
+def checksum64(a, first_word=0):
+    """(sum w_i, sum w_i * (2 i + 1)) mod 2^64 over the words of `a` in memory order (64-bit words for fp64, 32-bit words
+    for fp32), i counted from first_word -- bench.py restates this function on its product side"""
+    w = np.ascontiguousarray(a).reshape(-1)
+    w = w.view(np.uint64) if w.dtype.itemsize == 8 else w.view(np.uint32)
     s1 = np.uint64(0)
     s2 = np.uint64(0)
     step = 1 << 24
     with np.errstate(over="ignore"):
         for i in range(0, w.size, step):
-            c = w[i:i + step]
-            k = np.arange(i, i + c.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+            c = w[i:i + step].astype(np.uint64)
+            k = np.arange(first_word + i, first_word + i + c.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
             s1 = s1 + c.sum(dtype=np.uint64)
             s2 = s2 + (c * k).sum(dtype=np.uint64)
     return "%016x" % int(s1), "%016x" % int(s2)
 
 
-def case(n):
+def case(n, dtype=np.float64):
     nlev = O.num_grids(n)
-    v = O.cycle3d([n] * 3, R3, mode=0, v1=2, v2=2, reps=1, dtype=np.float64)
+    v = O.cycle3d([n] * 3, R3, mode=0, v1=2, v2=2, reps=1, dtype=dtype)
     s1, s2 = checksum64(v)
     return {
-        "n": n, "nlevels": nlev, "v1": 2, "v2": 2, "dtype": "f64", "fnv": O.fnv(v), "sum64": s1, "wsum64": s2,
-        "centre": float(v[n // 2, n // 2, n // 2]),
+        "n": n, "nlevels": nlev, "v1": 2, "v2": 2, "dtype": "f64" if dtype == np.float64 else "f32", "fnv": O.fnv(v),
+        "sum64": s1, "wsum64": s2, "centre": float(v[n // 2, n // 2, n // 2]),
         "block_fnv": [O.fnv(v[z:z + 64]) for z in range(0, n, 64)],
     }
 
 
 def main():
-    sizes = [int(a) for a in sys.argv[1:]] or [513, 1025]
+    """arguments: sizes, each optionally suffixed with the type, e.g. `513 1025 513:f32` (default f64).  fp32 cases are
+    restatement<float>, which is bit-identical to the compiled reference (tests/test_oracle_vs_ref.py)"""
+    todo = [a.split(":") for a in sys.argv[1:]] or [["513"], ["1025"]]
     data = {}
     if os.path.exists(OUT):
         with open(OUT) as fh:
             data = json.load(fh)
-    for n in sizes:
-        key = "3d_n%d_vcycle22_%dlev_f64" % (n, O.num_grids(n))
-        data[key] = case(n)
+    for t in todo:
+        n, dt = int(t[0]), (t[1] if len(t) > 1 else "f64")
+        key = "3d_n%d_vcycle22_%dlev_%s" % (n, O.num_grids(n), dt)
+        data[key] = case(n, np.float64 if dt == "f64" else np.float32)
         print(key, data[key]["fnv"], data[key]["centre"], flush=True)
         with open(OUT, "w") as fh:
             json.dump(data, fh, indent=1, sort_keys=True)

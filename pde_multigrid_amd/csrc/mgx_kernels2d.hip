@@ -245,6 +245,321 @@ __global__ void __launch_bounds__(256) abs_error2d_kernel(const real* __restrict
     }
 }
 
+// =========================================================================== cache-resident cycle kernels
+// At BASELINE's 1025^2 the hierarchy (22 MB in fp64) never leaves L2 / Infinity Cache, so the cycle is bound by the number
+// of launches and by cache latency, not by HBM: one launch per colour pass per level costs ~60 launches per V(2,2).
+// The upwind stencil {C, E = x+1, S = y+1} is ONE-SIDED, which makes temporal blocking cheap: a workgroup that loads a
+// T x T tile plus a halo of `npass` points on the +x / +y side only can run all 2*ncycles colour passes of a Relax call on
+// the tile in LDS (after pass c the entries closer than c+1 to the tile's high edge are stale, the rest are exactly the
+// values whole-grid passes produce: same per-point expression, same colour order -- bit-identical), and the operator
+// that follows or precedes the smoother in the cycle works on the same tile:
+//   cycle2d_down_kernel  Relax(v1) + CalculateResidual + Restrict      N2/MultiGrid2D.cpp:317-323   (one launch)
+//   cycle2d_up_kernel    Interpolate + ApplyCorrection + Relax(v2)     N2/MultiGrid2D.cpp:333-338   (one launch)
+//   cycle2d_tail_kernel  the whole V-cycle below 65^2 in ONE workgroup, every level's v and f in LDS   :314-340
+// Tiles overlap, so the kernels are out of place (vin -> vout; the host layer swaps the level's two arrays).
+// A 7-level V(2,2) at 1025^2 is 9 launches (4 levels x 2 + the tail) instead of ~60.
+constexpr int CYC2_MAXPASS = 8;  // colour passes per launch the tile halo is sized for (4 sweeps)
+
+template <class real>
+struct Pt2 {  // a point a thread owns: LDS offset (-1 = nothing to do) and its coefficients (N2/MultiGrid2D.cpp:230-236)
+    int off;
+    real hyK1, hxK2, den;
+};
+
+template <class real>
+__device__ __forceinline__ Pt2<real> make_pt2(const Lyap2<real>& k, int x, int y, int off) {
+    Pt2<real> p;
+    const real xj = k.ax + x * k.hx;  // :230-231
+    const real yi = k.ay + y * k.hy;
+    const real K1 = k.A0 * xj + k.A1 * yi;  // :233-234
+    const real K2 = k.A2 * xj + k.A3 * yi;
+    p.den = K1 * k.hy + K2 * k.hx - k.alfa * k.hx * k.hy;  // :236
+    p.hyK1 = k.hy * K1;
+    p.hxK2 = k.hx * K2;
+    p.off = off;
+    return p;
+}
+
+// the points of colour `c` this thread owns in a W x Wy tile whose origin is the global point (gx0, gy0): slot s is the
+// s-th of the tile's colour-c points taken NT apart; a point takes part if it is an interior point of the grid and its
+// E and S neighbours are inside the tile
+template <class real, int NT, int NP>
+__device__ __forceinline__ void own_points2(Pt2<real> (&pts)[NP], const Lyap2<real>& k, int c, int W, int Wy, int gx0, int gy0, int sx,
+                                            int sy) {
+    const int Wh = (W + 1) >> 1;
+#pragma unroll
+    for (int s = 0; s < NP; s++) {
+        const int idx = threadIdx.x + s * NT;
+        pts[s].off = -1;
+        pts[s].hyK1 = pts[s].hxK2 = pts[s].den = (real)0;
+        if (idx < Wh * Wy) {
+            const int ty = idx / Wh, i = idx - ty * Wh;
+            const int tx = 2 * i + ((c + gx0 + gy0 + ty) & 1);
+            const int x = gx0 + tx, y = gy0 + ty;
+            if (tx + 1 < W && ty + 1 < Wy && x >= 1 && x <= sx - 2 && y >= 1 && y <= sy - 2) pts[s] = make_pt2<real>(k, x, y, ty * W + tx);
+        }
+    }
+}
+
+template <class real, int NP>
+__device__ __forceinline__ void relax_owned2(real* sv, const real* sf, const Pt2<real> (&pts)[NP], int W, real hx, real hy) {
+#pragma unroll
+    for (int s = 0; s < NP; s++)
+        if (pts[s].off >= 0) {
+            const int t = pts[s].off;
+            sv[t] = (pts[s].hyK1 * sv[t + 1] + pts[s].hxK2 * sv[t + W] - sf[t] * hx * hy) / (pts[s].den);  // :241
+        }
+}
+
+template <class real, int T, int NT, int NP>
+__global__ void __launch_bounds__(NT) cycle2d_down_kernel(const real* __restrict__ vin, real* __restrict__ vout,
+                                                          const real* __restrict__ f, int sx, int sy, Lyap2<real> k, int npass,
+                                                          int v_zero, real* __restrict__ coarse, int cx, int cy) {
+    extern __shared__ __align__(16) unsigned char smem2[];
+    // tile = core [X0, X0+T) + 1 point below (the restriction reads residuals at 2p-1) + 2 + npass above (the residual at
+    // X0+T reads v at X0+T+1, and npass passes eat npass points of the high side)
+    const int W = T + 3 + npass;
+    real* sv = (real*)smem2;
+    real* sf = sv + W * W;
+    const int X0 = blockIdx.x * T, Y0 = blockIdx.y * T, gx0 = X0 - 1, gy0 = Y0 - 1;
+    for (int t = threadIdx.x; t < W * W; t += NT) {
+        const int ty = t / W, tx = t - ty * W, x = gx0 + tx, y = gy0 + ty;
+        real a = 0, b = 0;
+        if (x >= 0 && x < sx && y >= 0 && y < sy) {
+            const size_t i = x + (size_t)y * sx;
+            if (!v_zero) a = vin[i];
+            if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1) b = f[i];  // f of a boundary point is never read; 0 = its residual
+        }
+        sv[t] = a;
+        sf[t] = b;
+    }
+    Pt2<real> red[NP], black[NP];
+    own_points2<real, NT, NP>(red, k, 0, W, W, gx0, gy0, sx, sy);
+    own_points2<real, NT, NP>(black, k, 1, W, W, gx0, gy0, sx, sy);
+    __syncthreads();
+    for (int sweep = 0; sweep < npass / 2; sweep++) {  // red = (x + y) % 2 == 0 first (:223), then black (:250)
+        relax_owned2<real, NP>(sv, sf, red, W, k.hx, k.hy);
+        __syncthreads();
+        relax_owned2<real, NP>(sv, sf, black, W, k.hx, k.hy);
+        __syncthreads();
+    }
+    // the smoothed core; the last tile of a row / column also owns the boundary point sx-1 / sy-1
+    const int xe = blockIdx.x == gridDim.x - 1 ? sx : X0 + T, ye = blockIdx.y == gridDim.y - 1 ? sy : Y0 + T;
+    const int cw = xe - X0, ch = ye - Y0;
+    for (int t = threadIdx.x; t < cw * ch; t += NT) {
+        const int ly = t / cw, lx = t - ly * cw;
+        vout[(X0 + lx) + (size_t)(Y0 + ly) * sx] = sv[(ly + 1) * W + lx + 1];
+    }
+    if (!coarse) return;
+    // residual of the points [X0-1, X0+T]^2 in place of their f (:403); boundary points keep their 0 (:389-392)
+    const real hxhy_alfa = k.alfa * k.hx * k.hy;
+#pragma unroll
+    for (int s = 0; s < NP; s++) {
+        if (red[s].off >= 0) {
+            const int t = red[s].off;
+            sf[t] = sf[t] - (red[s].hyK1 * sv[t + 1] + red[s].hxK2 * sv[t + W] - sv[t] * (red[s].hyK1 + red[s].hxK2 - hxhy_alfa)) / (k.hx * k.hy);
+        }
+        if (black[s].off >= 0) {
+            const int t = black[s].off;
+            sf[t] = sf[t] - (black[s].hyK1 * sv[t + 1] + black[s].hxK2 * sv[t + W] - sv[t] * (black[s].hyK1 + black[s].hxK2 - hxhy_alfa)) / (k.hx * k.hy);
+        }
+    }
+    __syncthreads();
+    const int px0 = X0 >> 1, py0 = Y0 >> 1;
+    const int pw = blockIdx.x == gridDim.x - 1 ? cx - px0 : T / 2, ph = blockIdx.y == gridDim.y - 1 ? cy - py0 : T / 2;
+    for (int t = threadIdx.x; t < pw * ph; t += NT) {
+        const int ly = t / pw, lx = t - ly * pw;
+        const int px = px0 + lx, py = py0 + ly;
+        real out = (real)0;  // boundary coarse point: injection of a boundary residual, which is 0 (:389-392 then :95-101)
+        if (px > 0 && px < cx - 1 && py > 0 && py < cy - 1) {
+            const real* c = sf + (2 * ly + 1) * W + 2 * lx + 1;
+            const real C = c[0], N = c[-W], S = c[W], E = c[1], O = c[-1];
+            const real NE = c[1 - W], NO = c[-1 - W], SE = c[1 + W], SO = c[-1 + W];
+            out = (1 / 16.0f) * (NO + NE + SO + SE + 2 * (O + E + N + S) + 4 * C);  // :123
+        }
+        coarse[px + (size_t)py * cx] = out;
+    }
+}
+
+template <class real, int T, int NT, int NP>
+__global__ void __launch_bounds__(NT) cycle2d_up_kernel(const real* __restrict__ vin, real* __restrict__ vout,
+                                                        const real* __restrict__ f, int sx, int sy, Lyap2<real> k, int npass,
+                                                        const real* __restrict__ coarse, int cx, int cy) {
+    extern __shared__ __align__(16) unsigned char smem2[];
+    const int W = T + 1 + npass;        // core [X0, X0+T] + npass points above
+    const int Wc = (W - 1) / 2 + 2;     // coarse points under the tile
+    real* sv = (real*)smem2;
+    real* sf = sv + W * W;
+    real* sc = sf + W * W;
+    const int X0 = blockIdx.x * T, Y0 = blockIdx.y * T, px0 = X0 >> 1, py0 = Y0 >> 1;
+    for (int t = threadIdx.x; t < Wc * Wc; t += NT) {
+        const int ty = t / Wc, tx = t - ty * Wc, px = px0 + tx, py = py0 + ty;
+        sc[t] = (px < cx && py < cy) ? coarse[px + (size_t)py * cx] : (real)0;
+    }
+    for (int t = threadIdx.x; t < W * W; t += NT) {
+        const int ty = t / W, tx = t - ty * W, x = X0 + tx, y = Y0 + ty;
+        real a = 0, b = 0;
+        if (x < sx && y < sy) {
+            const size_t i = x + (size_t)y * sx;
+            a = vin[i];
+            if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1) b = f[i];
+        }
+        sv[t] = a;
+        sf[t] = b;
+    }
+    Pt2<real> red[NP], black[NP];
+    own_points2<real, NT, NP>(red, k, 0, W, W, X0, Y0, sx, sy);
+    own_points2<real, NT, NP>(black, k, 1, W, W, X0, Y0, sx, sy);
+    __syncthreads();
+    // v += Interpolate(coarse) on the interior points of the tile (N2/MultiGrid2D.cpp:153-192 then :363)
+    for (int t = threadIdx.x; t < W * W; t += NT) {
+        const int ty = t / W, tx = t - ty * W, x = X0 + tx, y = Y0 + ty;
+        if (x >= 1 && x <= sx - 2 && y >= 1 && y <= sy - 2) {
+            const real* c = sc + ((y >> 1) - py0) * Wc + ((x >> 1) - px0);
+            const bool ox = x & 1, oy = y & 1;
+            real e;
+            if (!oy && !ox) e = c[0];                                              // :153-156
+            else if (oy && !ox) e = (1 / 2.0f) * (c[0] + c[Wc]);                   // :158-166
+            else if (!oy && ox) e = (1 / 2.0f) * (c[0] + c[1]);                    // :169-177
+            else e = (1 / 4.0f) * (c[0] + c[1] + c[Wc] + c[Wc + 1]);               // :180-192
+            sv[t] = sv[t] + e;
+        }
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < npass / 2; sweep++) {
+        relax_owned2<real, NP>(sv, sf, red, W, k.hx, k.hy);
+        __syncthreads();
+        relax_owned2<real, NP>(sv, sf, black, W, k.hx, k.hy);
+        __syncthreads();
+    }
+    const int xe = blockIdx.x == gridDim.x - 1 ? sx : X0 + T, ye = blockIdx.y == gridDim.y - 1 ? sy : Y0 + T;
+    const int cw = xe - X0, ch = ye - Y0;
+    for (int t = threadIdx.x; t < cw * ch; t += NT) {
+        const int ly = t / cw, lx = t - ly * cw;
+        vout[(X0 + lx) + (size_t)(Y0 + ly) * sx] = sv[ly * W + lx];
+    }
+}
+
+// ---- the whole cycle below 65^2 in one workgroup ---------------------------------------------------------------------
+constexpr int TAIL2_MAXLEV = 8;
+template <class real>
+struct Tail2 {
+    int nlev;
+    int sx[TAIL2_MAXLEV], sy[TAIL2_MAXLEV];
+    real* v[TAIL2_MAXLEV];
+    real* f[TAIL2_MAXLEV];
+    real hx[TAIL2_MAXLEV], hy[TAIL2_MAXLEV];
+};
+
+template <class real>
+__device__ __forceinline__ void tail_relax2(real* sv, const real* sf, int sx, int sy, const Lyap2<real>& k, int ncycles) {
+    const int n = sx * sy;
+    for (int c = 0; c < 2 * ncycles; c++) {
+        const int colour = c & 1;
+        for (int t = threadIdx.x; t < n; t += 1024) {
+            const int y = t / sx, x = t - y * sx;
+            if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1 && ((x + y) & 1) == colour) {
+                const Pt2<real> p = make_pt2<real>(k, x, y, t);
+                sv[t] = (p.hyK1 * sv[t + 1] + p.hxK2 * sv[t + sx] - sf[t] * k.hx * k.hy) / (p.den);  // :241
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <class real>
+__global__ void __launch_bounds__(1024) cycle2d_tail_kernel(Tail2<real> L, Lyap2<real> k0, int v1, int v2, int top_zero) {
+    extern __shared__ __align__(16) unsigned char smem2[];
+    real* base = (real*)smem2;
+    int offv[TAIL2_MAXLEV], offf[TAIL2_MAXLEV];
+    {
+        int o = 0;
+#pragma unroll
+        for (int l = 0; l < TAIL2_MAXLEV; l++) {
+            offv[l] = o;
+            if (l < L.nlev) o += L.sx[l] * L.sy[l];
+            offf[l] = o;
+            if (l < L.nlev) o += L.sx[l] * L.sy[l];
+        }
+    }
+    {   // level 0 of the tail: v as it stands (or 0 when the caller knows it is the zeroed error of a coarse level), f
+        const int n = L.sx[0] * L.sy[0];
+        for (int t = threadIdx.x; t < n; t += 1024) {
+            base[offv[0] + t] = top_zero ? (real)0 : L.v[0][t];
+            base[offf[0] + t] = L.f[0][t];
+        }
+    }
+    __syncthreads();
+    const int last = L.nlev - 1;
+    for (int l = 0; l <= last; l++) {  // MultiGrid2D::VCycle, way down                      N2/MultiGrid2D.cpp:317-328
+        Lyap2<real> k = k0;
+        k.hx = L.hx[l];
+        k.hy = L.hy[l];
+        real* sv = base + offv[l];
+        real* sf = base + offf[l];
+        const int sx = L.sx[l], sy = L.sy[l];
+        tail_relax2<real>(sv, sf, sx, sy, k, v1);  // :317
+        if (l == last) {
+            tail_relax2<real>(sv, sf, sx, sy, k, v2);  // :338 on the coarsest level
+            break;
+        }
+        const int cx = L.sx[l + 1], cy = L.sy[l + 1];
+        real* cv = base + offv[l + 1];
+        real* cf = base + offf[l + 1];
+        auto res = [&](int x, int y) -> real {  // :403, 0 on the boundary (:389-392)
+            if (x == 0 || x == sx - 1 || y == 0 || y == sy - 1) return (real)0;
+            const int i = x + y * sx;
+            const Pt2<real> p = make_pt2<real>(k, x, y, i);
+            return sf[i] - (p.hyK1 * sv[i + 1] + p.hxK2 * sv[i + sx] - sv[i] * (p.hyK1 + p.hxK2 - k.alfa * k.hx * k.hy)) / (k.hx * k.hy);
+        };
+        for (int t = threadIdx.x; t < cx * cy; t += 1024) {
+            const int py = t / cx, px = t - py * cx;
+            real out = (real)0;
+            if (px > 0 && px < cx - 1 && py > 0 && py < cy - 1) {
+                const int x = 2 * px, y = 2 * py;
+                const real C = res(x, y), N = res(x, y - 1), S = res(x, y + 1), E = res(x + 1, y), O = res(x - 1, y);
+                const real NE = res(x + 1, y - 1), NO = res(x - 1, y - 1), SE = res(x + 1, y + 1), SO = res(x - 1, y + 1);
+                out = (1 / 16.0f) * (NO + NE + SO + SE + 2 * (O + E + N + S) + 4 * C);  // :123
+            }
+            cf[t] = out;       // :320-323
+            cv[t] = (real)0;   // :326
+        }
+        __syncthreads();
+    }
+    for (int l = last - 1; l >= 0; l--) {  // way up                                          N2/MultiGrid2D.cpp:333-338
+        Lyap2<real> k = k0;
+        k.hx = L.hx[l];
+        k.hy = L.hy[l];
+        real* sv = base + offv[l];
+        real* sf = base + offf[l];
+        const real* c = base + offv[l + 1];
+        const int sx = L.sx[l], sy = L.sy[l], cx = L.sx[l + 1];
+        for (int t = threadIdx.x; t < sx * sy; t += 1024) {
+            const int y = t / sx, x = t - y * sx;
+            if (x >= 1 && x <= sx - 2 && y >= 1 && y <= sy - 2) {
+                const int ci = (x >> 1) + (y >> 1) * cx;
+                const bool ox = x & 1, oy = y & 1;
+                real e;
+                if (!oy && !ox) e = c[ci];
+                else if (oy && !ox) e = (1 / 2.0f) * (c[ci] + c[ci + cx]);
+                else if (!oy && ox) e = (1 / 2.0f) * (c[ci] + c[ci + 1]);
+                else e = (1 / 4.0f) * (c[ci] + c[ci + 1] + c[ci + cx] + c[ci + cx + 1]);
+                sv[t] = sv[t] + e;  // :363
+            }
+        }
+        __syncthreads();
+        tail_relax2<real>(sv, sf, sx, sy, k, v2);  // :338
+    }
+    // what the launch-per-operator path leaves in the level arrays: v of every level, the restricted residual in f below the top
+    for (int l = 0; l <= last; l++) {
+        const int n = L.sx[l] * L.sy[l];
+        for (int t = threadIdx.x; t < n; t += 1024) {
+            L.v[l][t] = base[offv[l] + t];
+            if (l > 0) L.f[l][t] = base[offf[l] + t];
+        }
+    }
+}
+
 // =========================================================================== host side
 static inline dim3 blk2() { return dim3(64, 4, 1); }
 static inline dim3 grd2(int nx, int ny) { return dim3(ceil_div(nx, 64), ceil_div(ny, 4), 1); }
@@ -424,6 +739,120 @@ int mean_abs_error2d(mgx_ctx* ctx, const real* v, const int n[2], const real h[2
     return MGX_OK;
 }
 
+// ---- host side of the cache-resident cycle kernels ------------------------------------------------------------------
+template <class K>
+static int allow_lds(K kernel, size_t bytes) {  // dynamic LDS beyond the 64 KB default needs the attribute (160 KB per CU)
+    if (bytes > 64 * 1024) MGX_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MGX_OK;
+}
+
+// tile edge for an sx x sy level: about one workgroup per CU at 1025^2, smaller tiles below
+static int cyc2_tile(const int n[2]) {
+    const int m = n[0] > n[1] ? n[0] : n[1];
+    return m > 513 ? 64 : (m > 257 ? 32 : 16);
+}
+
+template <class real>
+int cycle2d_down(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const int n[2], const real h[2], const real a[2],
+                 const real A[4], int alfa, int ncycles, int v_zero, real* coarse_f, const int cn[2]) {
+    MGX_REQUIRE(ctx && vout && f && h && a && A && (vin || v_zero), MGX_ERR_INVALID, "relax_residual_restrict2d: NULL argument");
+    MGX_USE(ctx);
+    MGX_REQUIRE(vin != vout, MGX_ERR_INVALID, "relax_residual_restrict2d: v_in and v_out must differ (tiles overlap)");
+    int st = check_n2(n, "relax_residual_restrict2d");
+    if (st) return st;
+    if (coarse_f) {
+        st = check_coarse2(n, cn, "relax_residual_restrict2d");
+        if (st) return st;
+    }
+    MGX_REQUIRE(ncycles >= 0 && 2 * ncycles <= CYC2_MAXPASS, MGX_ERR_INVALID, "relax_residual_restrict2d: 0 <= ncycles <= %d", CYC2_MAXPASS / 2);
+    const Lyap2<real> k = lyap<real>(h, a, A, alfa);
+    const int npass = 2 * ncycles, T = cyc2_tile(n), W = T + 3 + npass;
+    const size_t lds = (size_t)2 * W * W * sizeof(real);
+    const dim3 g(max(1, ceil_div(n[0] - 1, T)), max(1, ceil_div(n[1] - 1, T)));
+    const int cx = coarse_f ? cn[0] : 0, cy = coarse_f ? cn[1] : 0;
+#define MGX_CYC_DOWN(TT, NT, NP)                                                                                              \
+    do {                                                                                                                      \
+        MGX_TRY_RET(allow_lds(cycle2d_down_kernel<real, TT, NT, NP>, lds));                                                   \
+        hipLaunchKernelGGL((cycle2d_down_kernel<real, TT, NT, NP>), g, dim3(NT), lds, ctx->compute, vin, vout, f, n[0], n[1], k, \
+                           npass, v_zero, coarse_f, cx, cy);                                                                  \
+    } while (0)
+    if (T == 64) MGX_CYC_DOWN(64, 1024, 3);        // 38 x 75 = 2850 points of a colour / 1024 threads
+    else if (T == 32) MGX_CYC_DOWN(32, 256, 4);    // 22 x 43 = 946 / 256
+    else MGX_CYC_DOWN(16, 256, 2);                 // 14 x 27 = 378 / 256
+#undef MGX_CYC_DOWN
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+template <class real>
+int cycle2d_up(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const int n[2], const real h[2], const real a[2],
+               const real A[4], int alfa, const real* coarse_v, const int cn[2], int ncycles) {
+    MGX_REQUIRE(ctx && vin && vout && f && h && a && A && coarse_v, MGX_ERR_INVALID, "interpolate_correct_relax2d: NULL argument");
+    MGX_USE(ctx);
+    MGX_REQUIRE(vin != vout, MGX_ERR_INVALID, "interpolate_correct_relax2d: v_in and v_out must differ (tiles overlap)");
+    int st = check_n2(n, "interpolate_correct_relax2d");
+    if (st) return st;
+    st = check_coarse2(n, cn, "interpolate_correct_relax2d");
+    if (st) return st;
+    MGX_REQUIRE(ncycles >= 0 && 2 * ncycles <= CYC2_MAXPASS, MGX_ERR_INVALID, "interpolate_correct_relax2d: 0 <= ncycles <= %d", CYC2_MAXPASS / 2);
+    const Lyap2<real> k = lyap<real>(h, a, A, alfa);
+    const int npass = 2 * ncycles, T = cyc2_tile(n), W = T + 1 + npass, Wc = (W - 1) / 2 + 2;
+    const size_t lds = ((size_t)2 * W * W + (size_t)Wc * Wc) * sizeof(real);
+    const dim3 g(max(1, ceil_div(n[0] - 1, T)), max(1, ceil_div(n[1] - 1, T)));
+#define MGX_CYC_UP(TT, NT, NP)                                                                                              \
+    do {                                                                                                                    \
+        MGX_TRY_RET(allow_lds(cycle2d_up_kernel<real, TT, NT, NP>, lds));                                                   \
+        hipLaunchKernelGGL((cycle2d_up_kernel<real, TT, NT, NP>), g, dim3(NT), lds, ctx->compute, vin, vout, f, n[0], n[1], k, \
+                           npass, coarse_v, cn[0], cn[1]);                                                                  \
+    } while (0)
+    if (T == 64) MGX_CYC_UP(64, 1024, 3);
+    else if (T == 32) MGX_CYC_UP(32, 256, 4);
+    else MGX_CYC_UP(16, 256, 2);
+#undef MGX_CYC_UP
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+// levels[0 .. nlev) of a hierarchy, finest of the tail first; n = {sx0, sy0, sx1, sy1, ...}, h likewise
+template <class real>
+int cycle2d_tail(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const int* n, const real* h, const real a[2],
+                 const real A[4], int alfa, int v1, int v2, int top_zero) {
+    MGX_REQUIRE(ctx && v && f && n && h && a && A, MGX_ERR_INVALID, "vcycle_tail2d: NULL argument");
+    MGX_USE(ctx);
+    MGX_REQUIRE(nlev >= 1 && nlev <= TAIL2_MAXLEV, MGX_ERR_INVALID, "vcycle_tail2d: 1 <= nlev <= %d", TAIL2_MAXLEV);
+    MGX_REQUIRE(v1 >= 0 && v2 >= 0, MGX_ERR_INVALID, "vcycle_tail2d: negative sweep count");
+    Tail2<real> L;
+    memset(&L, 0, sizeof L);
+    L.nlev = nlev;
+    size_t elems = 0;
+    for (int l = 0; l < nlev; l++) {
+        const int nl[2] = {n[2 * l], n[2 * l + 1]};
+        int st = check_n2(nl, "vcycle_tail2d");
+        if (st) return st;
+        if (l > 0) {
+            const int fl[2] = {n[2 * l - 2], n[2 * l - 1]};
+            st = check_coarse2(fl, nl, "vcycle_tail2d");
+            if (st) return st;
+        }
+        MGX_REQUIRE(v[l] && f[l], MGX_ERR_INVALID, "vcycle_tail2d: NULL level array");
+        L.sx[l] = nl[0];
+        L.sy[l] = nl[1];
+        L.v[l] = v[l];
+        L.f[l] = f[l];
+        L.hx[l] = h[2 * l];
+        L.hy[l] = h[2 * l + 1];
+        elems += (size_t)2 * nl[0] * nl[1];
+    }
+    const size_t lds = elems * sizeof(real);
+    MGX_REQUIRE(lds <= 150 * 1024, MGX_ERR_SIZE, "vcycle_tail2d: the levels need %zu bytes of LDS (> 150 KB)", lds);
+    const real h0[2] = {h[0], h[1]};
+    const Lyap2<real> k = lyap<real>(h0, a, A, alfa);
+    MGX_TRY_RET(allow_lds(cycle2d_tail_kernel<real>, lds));
+    hipLaunchKernelGGL((cycle2d_tail_kernel<real>), dim3(1), dim3(1024), lds, ctx->compute, L, k, v1, v2, top_zero);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
 }  // namespace mgx
 
 #define MGX_DEFINE_OPS2D(SFX, real)                                                                              \
@@ -460,6 +889,27 @@ int mean_abs_error2d(mgx_ctx* ctx, const real* v, const int n[2], const real h[2
                            const real a[2], const real A[4], int alfa, real omega, int ncycles) {                \
         return mgx::jacobi2d<real>(ctx, v, tmp, f, n, h, a, A, alfa, omega, ncycles);                            \
     }                                                                                                            \
+    int mgx2d_relax_residual_restrict_##SFX(mgx_ctx* ctx, const real* v_in, real* v_out, const real* f,          \
+                                            const int n[2], const real h[2], const real a[2], const real A[4],   \
+                                            int alfa, int ncycles, int v_zero, real* coarse_f, const int cn[2]) { \
+        return mgx::cycle2d_down<real>(ctx, v_in, v_out, f, n, h, a, A, alfa, ncycles, v_zero, coarse_f, cn);     \
+    }                                                                                                             \
+    int mgx2d_interpolate_correct_relax_##SFX(mgx_ctx* ctx, const real* v_in, real* v_out, const real* f,         \
+                                              const int n[2], const real h[2], const real a[2], const real A[4],  \
+                                              int alfa, const real* coarse_v, const int cn[2], int ncycles) {     \
+        return mgx::cycle2d_up<real>(ctx, v_in, v_out, f, n, h, a, A, alfa, coarse_v, cn, ncycles);               \
+    }                                                                                                             \
+    int mgx2d_vcycle_tail_##SFX(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const int* n,             \
+                                const real* h, const real a[2], const real A[4], int alfa, int v1, int v2,        \
+                                int top_zero) {                                                                   \
+        return mgx::cycle2d_tail<real>(ctx, nlev, v, f, n, h, a, A, alfa, v1, v2, top_zero);                      \
+    }                                                                                                             \
+    int mgx2d_vcycle_tail_fits_##SFX(int nlev, const int* n) {                                                    \
+        size_t e = 0;                                                                                             \
+        if (!n || nlev < 1 || nlev > mgx::TAIL2_MAXLEV) return 0;                                                 \
+        for (int l = 0; l < nlev; l++) e += (size_t)2 * n[2 * l] * n[2 * l + 1];                                  \
+        return e * sizeof(real) <= 150 * 1024;                                                                    \
+    }                                                                                                             \
     int mgx2d_mean_abs_error_##SFX(mgx_ctx* ctx, const real* v, const int n[2], const real h[2], const real a[2], \
                                    double* host_mean) {                                                          \
         return mgx::mean_abs_error2d<real>(ctx, v, n, h, a, host_mean);                                          \

@@ -342,6 +342,41 @@ class _Ops2D(_Ops):
         return self._run(ctx, [v, coarse], lambda x, c: fn(ctx._h, x, _ip(n), c, _ip(cn)), 0, _shape(n), dtype)
 
 
+def _ops2d_fused_down(self, ctx, v, f, n, rng, A, alfa, ncycles, v_zero=False, restrict=True, dtype=None):
+    """(v_out, coarse_f) of mgx2d_relax_residual_restrict"""
+    dtype = dtype or v.dtype
+    fn, ct = self._fn("relax_residual_restrict", dtype)
+    h, a, AA = self._geom(n, rng, A, dtype, ct)
+    cn = coarse_size(n)
+    pv, pf = ctx.to_device(np.ascontiguousarray(v, dtype)), ctx.to_device(np.ascontiguousarray(f, dtype))
+    po, pc = ctx.to_device(np.full(_shape(n), np.nan, dtype)), ctx.to_device(np.full(_shape(cn), np.nan, dtype))
+    try:
+        check(fn(ctx._h, pv, po, pf, _ip(n), h, a, AA, C.c_int(alfa), C.c_int(ncycles), C.c_int(int(v_zero)),
+                 pc if restrict else None, _ip(cn) if restrict else None))
+        return ctx.to_host(po, _shape(n), dtype), (ctx.to_host(pc, _shape(cn), dtype) if restrict else None)
+    finally:
+        for p in (pv, pf, po, pc):
+            ctx.free(p)
+
+
+def _ops2d_fused_up(self, ctx, v, f, n, rng, A, alfa, coarse, ncycles, dtype=None):
+    dtype = dtype or v.dtype
+    fn, ct = self._fn("interpolate_correct_relax", dtype)
+    h, a, AA = self._geom(n, rng, A, dtype, ct)
+    cn = coarse_size(n)
+    pv, pf = ctx.to_device(np.ascontiguousarray(v, dtype)), ctx.to_device(np.ascontiguousarray(f, dtype))
+    po, pc = ctx.to_device(np.full(_shape(n), np.nan, dtype)), ctx.to_device(np.ascontiguousarray(coarse, dtype))
+    try:
+        check(fn(ctx._h, pv, po, pf, _ip(n), h, a, AA, C.c_int(alfa), pc, _ip(cn), C.c_int(ncycles)))
+        return ctx.to_host(po, _shape(n), dtype)
+    finally:
+        for p in (pv, pf, po, pc):
+            ctx.free(p)
+
+
+_Ops2D.relax_residual_restrict = _ops2d_fused_down
+_Ops2D.interpolate_correct_relax = _ops2d_fused_up
+
 ops3d = _Ops3D()
 ops3dxs = _Ops3D(xsplit=True)
 ops2d = _Ops2D()
@@ -535,7 +570,9 @@ class MultiGrid2D(_MGBase):
         fn = getattr(lib, "mgMultiGrid2D_%s_create" % self._sfx)
         check(fn(ctx._h, _ip(finestGridSizeXY), _rp(rng, self._ct), _rp(A, self._ct), C.c_int(2), C.c_int(alfa),
                  C.byref(self._mg)))
-        self._mg.contents.fuse = int(bool(fuse))
+        # fuse: True = the library default (2: cache-resident cycle kernels), 1 = fused operators only, False / 0 = one
+        # launch per reference call
+        self._mg.contents.fuse = 2 if fuse is True else int(fuse)
         if nlevels:
             self.numGrids = nlevels
 

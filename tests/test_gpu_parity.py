@@ -423,6 +423,68 @@ def test_2d_fused_operators_vs_oracle(ctx, n2, dtype):
     assert bits_equal(P.ops2d.interpolate_correct(ctx, v, n2, c), want)
 
 
+@pytest.mark.parametrize("n2", [(3, 3), (9, 9), (17, 33), (65, 65), (129, 65), (33, 257), (257, 257), (513, 129), (1025, 513)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_2d_cache_resident_kernels_vs_oracle(ctx, n2, dtype):
+    """the LDS-tiled multi-sweep kernels of the 2D cycle == the reference calls they replace, on sizes that do and do not
+    fill the tiles (16 / 32 / 64 points), 0 ... 4 sweeps per launch:
+      relax_residual_restrict   = Relax(k), then Restrict(CalculateResidual(.))     N2/MultiGrid2D.cpp:317-323
+      interpolate_correct_relax = Relax(ApplyCorrection(Interpolate(.)), k)         N2/MultiGrid2D.cpp:333-338"""
+    rng = np.random.default_rng(sum(n2))
+    rg = [-1, 2, 0.5, 3]
+    cn = P.coarse_size(n2)
+    v = rng.uniform(-1, 1, O.shape(n2)).astype(dtype)
+    f = rng.uniform(-1, 1, O.shape(n2)).astype(dtype)
+    c = rng.uniform(-1, 1, O.shape(cn)).astype(dtype)
+    for k in (0, 1, 2, 4):
+        vk = O.relax2d(n2, rg, A2, 2, v, f, k, dtype=dtype)
+        got_v, got_c = P.ops2d.relax_residual_restrict(ctx, v, f, n2, rg, A2, 2, k)
+        assert bits_equal(got_v, vk), k
+        assert bits_equal(got_c, O.restrict2d(n2, O.residual2d(n2, rg, A2, 2, vk, f, dtype=dtype), dtype=dtype)), k
+        got_v, _ = P.ops2d.relax_residual_restrict(ctx, v, f, n2, rg, A2, 2, k, restrict=False)
+        assert bits_equal(got_v, vk), k
+        z = np.zeros_like(v)  # v_zero: the input is not read and counts as the zeroed coarse error
+        zk = O.relax2d(n2, rg, A2, 2, z, f, k, dtype=dtype)
+        got_v, got_c = P.ops2d.relax_residual_restrict(ctx, np.full_like(v, np.nan), f, n2, rg, A2, 2, k, v_zero=True)
+        assert bits_equal(got_v, zk), k
+        assert bits_equal(got_c, O.restrict2d(n2, O.residual2d(n2, rg, A2, 2, zk, f, dtype=dtype), dtype=dtype)), k
+        want = O.relax2d(n2, rg, A2, 2, O.correct2d(n2, v, O.interpolate2d(n2, np.zeros(O.shape(n2), dtype), c, dtype=dtype), dtype=dtype),
+                         f, k, dtype=dtype)
+        assert bits_equal(P.ops2d.interpolate_correct_relax(ctx, v, f, n2, rg, A2, 2, c, k), want), k
+    with pytest.raises(P.MgxError) as e:  # the tile halo is sized for 4 sweeps
+        P.ops2d.relax_residual_restrict(ctx, v, f, n2, rg, A2, 2, 5)
+    assert e.value.status == P.MGX_ERR_INVALID
+
+
+@pytest.mark.parametrize("fuse", [2, 1, 0])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_2d_cycle_paths_agree_with_oracle(ctx, fuse, dtype):
+    """the three ways the host layer can run VCycle (cache-resident kernels / fused operators / one launch per reference
+    call) on hierarchies that end in the one-workgroup tail, start inside it, or end on a level too big for it"""
+    rg = [0, 1, 0, 2]
+    cases = [((257, 257), 0, 2, 2), ((129, 65), 0, 1, 3), ((65, 65), 0, 2, 2), ((33, 17), 0, 0, 2), ((9, 9), 0, 2, 0),
+             ((257, 129), 2, 2, 2), ((513, 513), 1, 1, 1), ((129, 129), 3, 2, 1), ((129, 129), 0, 4, 4)]
+    for n2, nlev, v1, v2 in cases:
+        rng = np.random.default_rng(sum(n2) + nlev)
+        v = rng.uniform(-1, 1, O.shape(n2)).astype(dtype)
+        f = rng.uniform(-1, 1, O.shape(n2)).astype(dtype)
+        mg = P.MultiGrid2D(ctx, n2, rg, A2, 2, dtype, nlevels=nlev, fuse=fuse)
+        mg.upload_v(0, v)
+        mg.upload_f(0, f)
+        for _ in range(2):
+            mg.VCycle(0, v1, v2)
+        want = O.cycle2d(n2, rg, A2, 2, nlevels=nlev, mode=0, v1=v1, v2=v2, reps=2, v=v, f=f, dtype=dtype)
+        assert bits_equal(mg.download_v(0), want), (n2, nlev, v1, v2)
+        mg.close()
+        mg = P.MultiGrid2D(ctx, n2, rg, A2, 2, dtype, nlevels=nlev, fuse=fuse)  # FMG on a fresh hierarchy: VCycle from every level
+        mg.upload_v(0, v)
+        mg.upload_f(0, f)
+        mg.FullMultiGridVCycle(0, 2, v1, v2)
+        want = O.cycle2d(n2, rg, A2, 2, nlevels=nlev, mode=1, v0=2, v1=v1, v2=v2, f=f, v=v, dtype=dtype)
+        assert bits_equal(mg.download_v(0), want), ("fmg", n2, nlev, v1, v2)
+        mg.close()
+
+
 def test_2d_unfused_cycle_path_still_matches(ctx):
     mg = P.MultiGrid2D(ctx, [129] * 2, [0, 1, 0, 1], A2, 2, np.float64, fuse=False)
     mg.FullMultiGridVCycle(0, 1, 2, 2)
