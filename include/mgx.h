@@ -82,7 +82,9 @@ int mgx_ctx_device(const mgx_ctx* ctx, int* device);
 /* tuning knobs of the x-split smoother kernel (speed only, never results): "relax3d.ty" waves
  * per block and "relax3d.rows" consecutive rows per lane, each in {1,2,4,8}; "relax3d.zchunk"
  * planes per block (0 = automatic); "relax3d.xcd" 0/1/2 block-to-tile mapping (2 = every XCD owns a y-slab and walks z);
- * "relax3d.wave_planes" slab height of the time-skewed pass order (< 0 automatic, 0 = whole-grid passes) */
+ * "relax3d.wave_planes" slab height of the time-skewed pass order (< 0 automatic, 0 = whole-grid passes);
+ * "cycle2d.tile" tile edge of the cache-resident 2D kernels (0 = by level size, 16, 32, 64), "cycle2d.tail_points" largest
+ * top level (in points, <= 5120) the one-workgroup tail kernel of the 2D cycle takes */
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value);
 /* name (kernel<template arguments>) of the smoother kernel the most recent 3D x-split colour pass launched; "" if none.
  * bench.py reports it as roofline.kernel so that the PMC traffic figure is attached only to the kernel it was taken from */
@@ -265,7 +267,8 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     /*   vcycle_tail: the whole VCycle(v1, v2) over levels[0 .. nlev) -- each at most 65^2, n and h     */ \
     /*     flattened {x0, y0, x1, y1, ...}, v / f HOST arrays of device pointers -- in ONE workgroup     */ \
     /*     with every level in LDS (:314-340); leaves v of all levels and f of levels 1.. as the        */ \
-    /*     launch-per-operator cycle does.  _fits: do the levels fit into LDS (1) or not (0)            */ \
+    /*     launch-per-operator cycle does.  _fits: may these levels run as one tail launch (they fit    */ \
+    /*     into LDS and the top level has at most "cycle2d.tail_points" points: 1) or not (0)           */ \
     int mgx2d_relax_residual_restrict_##SFX(mgx_ctx* ctx, const real* v_in, real* v_out, const real* f, \
                                             const int n[2], const real h[2], const real a[2],           \
                                             const real A[4], int alfa, int ncycles, int v_zero,         \
@@ -277,7 +280,7 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx2d_vcycle_tail_##SFX(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const int* n,   \
                                 const real* h, const real a[2], const real A[4], int alfa, int v1,      \
                                 int v2, int top_zero);                                                  \
-    int mgx2d_vcycle_tail_fits_##SFX(int nlev, const int* n);                                           \
+    int mgx2d_vcycle_tail_fits_##SFX(const mgx_ctx* ctx, int nlev, const int* n);                       \
     int mgx2d_interpolate_##SFX(mgx_ctx* ctx, real* fine, const int fn[2], const real* coarse,          \
                                 const int cn[2]);                                                       \
     int mgx2d_apply_correction_##SFX(mgx_ctx* ctx, real* fine, const int fn[2], const real* err,        \

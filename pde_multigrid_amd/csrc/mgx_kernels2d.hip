@@ -322,16 +322,28 @@ __global__ void __launch_bounds__(NT) cycle2d_down_kernel(const real* __restrict
     real* sv = (real*)smem2;
     real* sf = sv + W * W;
     const int X0 = blockIdx.x * T, Y0 = blockIdx.y * T, gx0 = X0 - 1, gy0 = Y0 - 1;
-    for (int t = threadIdx.x; t < W * W; t += NT) {
-        const int ty = t / W, tx = t - ty * W, x = gx0 + tx, y = gy0 + ty;
-        real a = 0, b = 0;
-        if (x >= 0 && x < sx && y >= 0 && y < sy) {
-            const size_t i = x + (size_t)y * sx;
-            if (!v_zero) a = vin[i];
-            if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1) b = f[i];  // f of a boundary point is never read; 0 = its residual
+    {   // all loads of the thread are issued before the first one is waited for (the tile comes from L2 / Infinity Cache)
+        constexpr int WM = T + 3 + CYC2_MAXPASS, NL = (WM * WM + NT - 1) / NT;
+        real a[NL], b[NL];
+#pragma unroll
+        for (int s = 0; s < NL; s++) {
+            const int t = threadIdx.x + s * NT;
+            const int ty = t / W, tx = t - ty * W, x = gx0 + tx, y = gy0 + ty;
+            a[s] = b[s] = (real)0;
+            if (t < W * W && x >= 0 && x < sx && y >= 0 && y < sy) {
+                const size_t i = x + (size_t)y * sx;
+                if (!v_zero) a[s] = vin[i];
+                if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1) b[s] = f[i];  // f of a boundary point is never read; 0 = its residual
+            }
         }
-        sv[t] = a;
-        sf[t] = b;
+#pragma unroll
+        for (int s = 0; s < NL; s++) {
+            const int t = threadIdx.x + s * NT;
+            if (t < W * W) {
+                sv[t] = a[s];
+                sf[t] = b[s];
+            }
+        }
     }
     Pt2<real> red[NP], black[NP];
     own_points2<real, NT, NP>(red, k, 0, W, W, gx0, gy0, sx, sy);
@@ -392,20 +404,39 @@ __global__ void __launch_bounds__(NT) cycle2d_up_kernel(const real* __restrict__
     real* sf = sv + W * W;
     real* sc = sf + W * W;
     const int X0 = blockIdx.x * T, Y0 = blockIdx.y * T, px0 = X0 >> 1, py0 = Y0 >> 1;
-    for (int t = threadIdx.x; t < Wc * Wc; t += NT) {
-        const int ty = t / Wc, tx = t - ty * Wc, px = px0 + tx, py = py0 + ty;
-        sc[t] = (px < cx && py < cy) ? coarse[px + (size_t)py * cx] : (real)0;
-    }
-    for (int t = threadIdx.x; t < W * W; t += NT) {
-        const int ty = t / W, tx = t - ty * W, x = X0 + tx, y = Y0 + ty;
-        real a = 0, b = 0;
-        if (x < sx && y < sy) {
-            const size_t i = x + (size_t)y * sx;
-            a = vin[i];
-            if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1) b = f[i];
+    {
+        constexpr int WM = T + 1 + CYC2_MAXPASS, NL = (WM * WM + NT - 1) / NT, WCM = (WM - 1) / 2 + 2, NLC = (WCM * WCM + NT - 1) / NT;
+        real a[NL], b[NL], cc[NLC];
+#pragma unroll
+        for (int s = 0; s < NLC; s++) {
+            const int t = threadIdx.x + s * NT;
+            const int ty = t / Wc, tx = t - ty * Wc, px = px0 + tx, py = py0 + ty;
+            cc[s] = (t < Wc * Wc && px < cx && py < cy) ? coarse[px + (size_t)py * cx] : (real)0;
         }
-        sv[t] = a;
-        sf[t] = b;
+#pragma unroll
+        for (int s = 0; s < NL; s++) {
+            const int t = threadIdx.x + s * NT;
+            const int ty = t / W, tx = t - ty * W, x = X0 + tx, y = Y0 + ty;
+            a[s] = b[s] = (real)0;
+            if (t < W * W && x < sx && y < sy) {
+                const size_t i = x + (size_t)y * sx;
+                a[s] = vin[i];
+                if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1) b[s] = f[i];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NLC; s++) {
+            const int t = threadIdx.x + s * NT;
+            if (t < Wc * Wc) sc[t] = cc[s];
+        }
+#pragma unroll
+        for (int s = 0; s < NL; s++) {
+            const int t = threadIdx.x + s * NT;
+            if (t < W * W) {
+                sv[t] = a[s];
+                sf[t] = b[s];
+            }
+        }
     }
     Pt2<real> red[NP], black[NP];
     own_points2<real, NT, NP>(red, k, 0, W, W, X0, Y0, sx, sy);
@@ -451,18 +482,38 @@ struct Tail2 {
     real hx[TAIL2_MAXLEV], hy[TAIL2_MAXLEV];
 };
 
+constexpr int TAIL2_PT = 5;  // points per thread of the largest tail level (65^2 = 4225 <= 5 x 1024)
+
+// the points thread t owns on an sx x sy level held in LDS (t, t + 1024, ...): colour of an interior point or -1
 template <class real>
-__device__ __forceinline__ void tail_relax2(real* sv, const real* sf, int sx, int sy, const Lyap2<real>& k, int ncycles) {
-    const int n = sx * sy;
-    for (int c = 0; c < 2 * ncycles; c++) {
-        const int colour = c & 1;
-        for (int t = threadIdx.x; t < n; t += 1024) {
+__device__ __forceinline__ void tail_points2(Pt2<real> (&pts)[TAIL2_PT], int (&kind)[TAIL2_PT], int sx, int sy, const Lyap2<real>& k) {
+#pragma unroll
+    for (int s = 0; s < TAIL2_PT; s++) {
+        const int t = threadIdx.x + s * 1024;
+        kind[s] = -1;
+        pts[s].off = t;
+        pts[s].hyK1 = pts[s].hxK2 = pts[s].den = (real)0;
+        if (t < sx * sy) {
             const int y = t / sx, x = t - y * sx;
-            if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1 && ((x + y) & 1) == colour) {
-                const Pt2<real> p = make_pt2<real>(k, x, y, t);
-                sv[t] = (p.hyK1 * sv[t + 1] + p.hxK2 * sv[t + sx] - sf[t] * k.hx * k.hy) / (p.den);  // :241
+            if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1) {
+                kind[s] = (x + y) & 1;
+                pts[s] = make_pt2<real>(k, x, y, t);
             }
         }
+    }
+}
+
+template <class real>
+__device__ __forceinline__ void tail_relax2(real* sv, const real* sf, int sx, const Pt2<real> (&pts)[TAIL2_PT],
+                                            const int (&kind)[TAIL2_PT], const Lyap2<real>& k, int ncycles) {
+    for (int c = 0; c < 2 * ncycles; c++) {
+        const int colour = c & 1;  // red = (x + y) % 2 == 0 first (:223), then black (:250)
+#pragma unroll
+        for (int s = 0; s < TAIL2_PT; s++)
+            if (kind[s] == colour) {
+                const int t = pts[s].off;
+                sv[t] = (pts[s].hyK1 * sv[t + 1] + pts[s].hxK2 * sv[t + sx] - sf[t] * k.hx * k.hy) / (pts[s].den);  // :241
+            }
         __syncthreads();
     }
 }
@@ -472,16 +523,15 @@ __global__ void __launch_bounds__(1024) cycle2d_tail_kernel(Tail2<real> L, Lyap2
     extern __shared__ __align__(16) unsigned char smem2[];
     real* base = (real*)smem2;
     int offv[TAIL2_MAXLEV], offf[TAIL2_MAXLEV];
-    {
-        int o = 0;
+    int o = 0;
 #pragma unroll
-        for (int l = 0; l < TAIL2_MAXLEV; l++) {
-            offv[l] = o;
-            if (l < L.nlev) o += L.sx[l] * L.sy[l];
-            offf[l] = o;
-            if (l < L.nlev) o += L.sx[l] * L.sy[l];
-        }
+    for (int l = 0; l < TAIL2_MAXLEV; l++) {
+        offv[l] = o;
+        if (l < L.nlev) o += L.sx[l] * L.sy[l];
+        offf[l] = o;
+        if (l < L.nlev) o += L.sx[l] * L.sy[l];
     }
+    real* sr = base + o;  // residual scratch, as large as the top level
     {   // level 0 of the tail: v as it stands (or 0 when the caller knows it is the zeroed error of a coarse level), f
         const int n = L.sx[0] * L.sy[0];
         for (int t = threadIdx.x; t < n; t += 1024) {
@@ -491,6 +541,8 @@ __global__ void __launch_bounds__(1024) cycle2d_tail_kernel(Tail2<real> L, Lyap2
     }
     __syncthreads();
     const int last = L.nlev - 1;
+    Pt2<real> pts[TAIL2_PT];
+    int kind[TAIL2_PT];
     for (int l = 0; l <= last; l++) {  // MultiGrid2D::VCycle, way down                      N2/MultiGrid2D.cpp:317-328
         Lyap2<real> k = k0;
         k.hx = L.hx[l];
@@ -498,27 +550,35 @@ __global__ void __launch_bounds__(1024) cycle2d_tail_kernel(Tail2<real> L, Lyap2
         real* sv = base + offv[l];
         real* sf = base + offf[l];
         const int sx = L.sx[l], sy = L.sy[l];
-        tail_relax2<real>(sv, sf, sx, sy, k, v1);  // :317
+        tail_points2<real>(pts, kind, sx, sy, k);
+        tail_relax2<real>(sv, sf, sx, pts, kind, k, v1);  // :317
         if (l == last) {
-            tail_relax2<real>(sv, sf, sx, sy, k, v2);  // :338 on the coarsest level
+            tail_relax2<real>(sv, sf, sx, pts, kind, k, v2);  // :338 on the coarsest level
             break;
         }
+        // residual (:403; 0 on the boundary, :389-392) into the scratch, then full weighting (:123)
+        const real hxhy_alfa = k.alfa * k.hx * k.hy;
+#pragma unroll
+        for (int s = 0; s < TAIL2_PT; s++) {
+            const int t = pts[s].off;
+            if (t < sx * sy) {
+                real r = (real)0;
+                if (kind[s] >= 0)
+                    r = sf[t] - (pts[s].hyK1 * sv[t + 1] + pts[s].hxK2 * sv[t + sx] - sv[t] * (pts[s].hyK1 + pts[s].hxK2 - hxhy_alfa)) / (k.hx * k.hy);
+                sr[t] = r;
+            }
+        }
+        __syncthreads();
         const int cx = L.sx[l + 1], cy = L.sy[l + 1];
         real* cv = base + offv[l + 1];
         real* cf = base + offf[l + 1];
-        auto res = [&](int x, int y) -> real {  // :403, 0 on the boundary (:389-392)
-            if (x == 0 || x == sx - 1 || y == 0 || y == sy - 1) return (real)0;
-            const int i = x + y * sx;
-            const Pt2<real> p = make_pt2<real>(k, x, y, i);
-            return sf[i] - (p.hyK1 * sv[i + 1] + p.hxK2 * sv[i + sx] - sv[i] * (p.hyK1 + p.hxK2 - k.alfa * k.hx * k.hy)) / (k.hx * k.hy);
-        };
         for (int t = threadIdx.x; t < cx * cy; t += 1024) {
             const int py = t / cx, px = t - py * cx;
-            real out = (real)0;
+            real out = (real)0;  // boundary: injection of a boundary residual, which is 0 (:95-101)
             if (px > 0 && px < cx - 1 && py > 0 && py < cy - 1) {
-                const int x = 2 * px, y = 2 * py;
-                const real C = res(x, y), N = res(x, y - 1), S = res(x, y + 1), E = res(x + 1, y), O = res(x - 1, y);
-                const real NE = res(x + 1, y - 1), NO = res(x - 1, y - 1), SE = res(x + 1, y + 1), SO = res(x - 1, y + 1);
+                const real* c = sr + 2 * px + 2 * py * sx;
+                const real C = c[0], N = c[-sx], S = c[sx], E = c[1], O = c[-1];
+                const real NE = c[1 - sx], NO = c[-1 - sx], SE = c[1 + sx], SO = c[-1 + sx];
                 out = (1 / 16.0f) * (NO + NE + SO + SE + 2 * (O + E + N + S) + 4 * C);  // :123
             }
             cf[t] = out;       // :320-323
@@ -534,21 +594,23 @@ __global__ void __launch_bounds__(1024) cycle2d_tail_kernel(Tail2<real> L, Lyap2
         real* sf = base + offf[l];
         const real* c = base + offv[l + 1];
         const int sx = L.sx[l], sy = L.sy[l], cx = L.sx[l + 1];
-        for (int t = threadIdx.x; t < sx * sy; t += 1024) {
-            const int y = t / sx, x = t - y * sx;
-            if (x >= 1 && x <= sx - 2 && y >= 1 && y <= sy - 2) {
+        tail_points2<real>(pts, kind, sx, sy, k);
+#pragma unroll
+        for (int s = 0; s < TAIL2_PT; s++)
+            if (kind[s] >= 0) {
+                const int t = pts[s].off;
+                const int y = t / sx, x = t - y * sx;
                 const int ci = (x >> 1) + (y >> 1) * cx;
                 const bool ox = x & 1, oy = y & 1;
                 real e;
-                if (!oy && !ox) e = c[ci];
-                else if (oy && !ox) e = (1 / 2.0f) * (c[ci] + c[ci + cx]);
-                else if (!oy && ox) e = (1 / 2.0f) * (c[ci] + c[ci + 1]);
-                else e = (1 / 4.0f) * (c[ci] + c[ci + 1] + c[ci + cx] + c[ci + cx + 1]);
+                if (!oy && !ox) e = c[ci];                                                   // :153-156
+                else if (oy && !ox) e = (1 / 2.0f) * (c[ci] + c[ci + cx]);                   // :158-166
+                else if (!oy && ox) e = (1 / 2.0f) * (c[ci] + c[ci + 1]);                    // :169-177
+                else e = (1 / 4.0f) * (c[ci] + c[ci + 1] + c[ci + cx] + c[ci + cx + 1]);     // :180-192
                 sv[t] = sv[t] + e;  // :363
             }
-        }
         __syncthreads();
-        tail_relax2<real>(sv, sf, sx, sy, k, v2);  // :338
+        tail_relax2<real>(sv, sf, sx, pts, kind, k, v2);  // :338
     }
     // what the launch-per-operator path leaves in the level arrays: v of every level, the restricted residual in f below the top
     for (int l = 0; l <= last; l++) {
@@ -746,10 +808,13 @@ static int allow_lds(K kernel, size_t bytes) {  // dynamic LDS beyond the 64 KB 
     return MGX_OK;
 }
 
-// tile edge for an sx x sy level: about one workgroup per CU at 1025^2, smaller tiles below
-static int cyc2_tile(const int n[2]) {
+// tile edge for an sx x sy level.  Measured on MI355X (tools/time_2d.py, profiles/r02_2d_*.txt): 64-point tiles (one
+// 1024-thread workgroup per CU) from 1025^2 up, 16-point tiles (256 threads, several workgroups per CU) below; 32-point
+// tiles lose at every size (one wave per SIMD: nothing hides the LDS latency chain of a pass)
+static int cyc2_tile(const mgx_ctx* ctx, const int n[2]) {
+    if (ctx->cyc2_tile == 16 || ctx->cyc2_tile == 32 || ctx->cyc2_tile == 64) return ctx->cyc2_tile;  // "cycle2d.tile"
     const int m = n[0] > n[1] ? n[0] : n[1];
-    return m > 513 ? 64 : (m > 257 ? 32 : 16);
+    return m > 513 ? 64 : 16;
 }
 
 template <class real>
@@ -766,7 +831,7 @@ int cycle2d_down(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const
     }
     MGX_REQUIRE(ncycles >= 0 && 2 * ncycles <= CYC2_MAXPASS, MGX_ERR_INVALID, "relax_residual_restrict2d: 0 <= ncycles <= %d", CYC2_MAXPASS / 2);
     const Lyap2<real> k = lyap<real>(h, a, A, alfa);
-    const int npass = 2 * ncycles, T = cyc2_tile(n), W = T + 3 + npass;
+    const int npass = 2 * ncycles, T = cyc2_tile(ctx, n), W = T + 3 + npass;
     const size_t lds = (size_t)2 * W * W * sizeof(real);
     const dim3 g(max(1, ceil_div(n[0] - 1, T)), max(1, ceil_div(n[1] - 1, T)));
     const int cx = coarse_f ? cn[0] : 0, cy = coarse_f ? cn[1] : 0;
@@ -796,7 +861,7 @@ int cycle2d_up(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const i
     if (st) return st;
     MGX_REQUIRE(ncycles >= 0 && 2 * ncycles <= CYC2_MAXPASS, MGX_ERR_INVALID, "interpolate_correct_relax2d: 0 <= ncycles <= %d", CYC2_MAXPASS / 2);
     const Lyap2<real> k = lyap<real>(h, a, A, alfa);
-    const int npass = 2 * ncycles, T = cyc2_tile(n), W = T + 1 + npass, Wc = (W - 1) / 2 + 2;
+    const int npass = 2 * ncycles, T = cyc2_tile(ctx, n), W = T + 1 + npass, Wc = (W - 1) / 2 + 2;
     const size_t lds = ((size_t)2 * W * W + (size_t)Wc * Wc) * sizeof(real);
     const dim3 g(max(1, ceil_div(n[0] - 1, T)), max(1, ceil_div(n[1] - 1, T)));
 #define MGX_CYC_UP(TT, NT, NP)                                                                                              \
@@ -843,6 +908,8 @@ int cycle2d_tail(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const i
         L.hy[l] = h[2 * l + 1];
         elems += (size_t)2 * nl[0] * nl[1];
     }
+    elems += (size_t)n[0] * n[1];  // the residual scratch
+    MGX_REQUIRE((size_t)n[0] * n[1] <= (size_t)TAIL2_PT * 1024, MGX_ERR_SIZE, "vcycle_tail2d: the top level has more than %d points", TAIL2_PT * 1024);
     const size_t lds = elems * sizeof(real);
     MGX_REQUIRE(lds <= 150 * 1024, MGX_ERR_SIZE, "vcycle_tail2d: the levels need %zu bytes of LDS (> 150 KB)", lds);
     const real h0[2] = {h[0], h[1]};
@@ -904,9 +971,10 @@ int cycle2d_tail(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const i
                                 int top_zero) {                                                                   \
         return mgx::cycle2d_tail<real>(ctx, nlev, v, f, n, h, a, A, alfa, v1, v2, top_zero);                      \
     }                                                                                                             \
-    int mgx2d_vcycle_tail_fits_##SFX(int nlev, const int* n) {                                                    \
-        size_t e = 0;                                                                                             \
-        if (!n || nlev < 1 || nlev > mgx::TAIL2_MAXLEV) return 0;                                                 \
+    int mgx2d_vcycle_tail_fits_##SFX(const mgx_ctx* ctx, int nlev, const int* n) {                                \
+        if (!ctx || !n || nlev < 1 || nlev > mgx::TAIL2_MAXLEV) return 0;                                         \
+        size_t e = (size_t)n[0] * n[1];                                                                           \
+        if (e > (size_t)mgx::TAIL2_PT * 1024 || e > (size_t)ctx->cyc2_tail_points) return 0;                      \
         for (int l = 0; l < nlev; l++) e += (size_t)2 * n[2 * l] * n[2 * l + 1];                                  \
         return e * sizeof(real) <= 150 * 1024;                                                                    \
     }                                                                                                             \

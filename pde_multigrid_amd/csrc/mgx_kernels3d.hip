@@ -2080,6 +2080,12 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "residual_restrict3d.pzchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "residual_restrict3d.pzchunk must be >= 0 (0 = automatic)");
         ctx->rr_pzchunk = value;
+    } else if (!strcmp(name, "cycle2d.tile")) {
+        MGX_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64, MGX_ERR_INVALID, "cycle2d.tile must be 0 (automatic), 16, 32 or 64");
+        ctx->cyc2_tile = value;
+    } else if (!strcmp(name, "cycle2d.tail_points")) {
+        MGX_REQUIRE(value >= 0 && value <= 5120, MGX_ERR_INVALID, "cycle2d.tail_points must be in [0, 5120]");
+        ctx->cyc2_tail_points = value;
     } else if (!strcmp(name, "relax3d.zchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "relax3d.zchunk must be >= 0 (0 = automatic)");
         ctx->relax_zchunk = value;

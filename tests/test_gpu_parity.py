@@ -456,12 +456,24 @@ def test_2d_cache_resident_kernels_vs_oracle(ctx, n2, dtype):
     assert e.value.status == P.MGX_ERR_INVALID
 
 
-@pytest.mark.parametrize("fuse", [2, 1, 0])
+@pytest.mark.parametrize("fuse,params", [(2, {}), (1, {}), (0, {}), (2, {"cycle2d.tail_points": 4225}), (2, {"cycle2d.tail_points": 0}),
+                                         (2, {"cycle2d.tile": 32}), (2, {"cycle2d.tile": 64, "cycle2d.tail_points": 289})])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_2d_cycle_paths_agree_with_oracle(ctx, fuse, dtype):
+def test_2d_cycle_paths_agree_with_oracle(ctx, fuse, params, dtype):
     """the three ways the host layer can run VCycle (cache-resident kernels / fused operators / one launch per reference
-    call) on hierarchies that end in the one-workgroup tail, start inside it, or end on a level too big for it"""
+    call) on hierarchies that end in the one-workgroup tail, start inside it, or end on a level too big for it; the
+    cache-resident path also with every tile size and with the tail starting at 65^2, at 17^2 and not at all"""
     rg = [0, 1, 0, 2]
+    for k_, v_ in params.items():
+        ctx.set_param(k_, v_)
+    try:
+        _cycle_paths_2d(ctx, fuse, dtype, rg)
+    finally:
+        ctx.set_param("cycle2d.tile", 0)
+        ctx.set_param("cycle2d.tail_points", 33 * 33)
+
+
+def _cycle_paths_2d(ctx, fuse, dtype, rg):
     cases = [((257, 257), 0, 2, 2), ((129, 65), 0, 1, 3), ((65, 65), 0, 2, 2), ((33, 17), 0, 0, 2), ((9, 9), 0, 2, 0),
              ((257, 129), 2, 2, 2), ((513, 513), 1, 1, 1), ((129, 129), 3, 2, 1), ((129, 129), 0, 4, 4)]
     for n2, nlev, v1, v2 in cases:

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pde_multigrid_amd as P  # noqa: E402
 
 ctx = P.Context(0)
-sizes = [int(a) for a in sys.argv[1:]] or [1025, 2049, 4097]
+sizes = [int(a) for a in sys.argv[1:]] or [1025, 2049, 4097]  # MGX_PARAMS=name=value,... sets context parameters
 
 
 def timed(fn, reps):
@@ -34,6 +34,8 @@ def lups(n, nlev):
     return 4 * tot
 
 
+for k, v in [a.split("=") for a in os.environ.get("MGX_PARAMS", "").split(",") if a]:
+    ctx.set_param(k, int(v))
 for n in sizes:
     nlev = 7 if n == 1025 else 0
     for dtype, name in ((np.float64, "f64"), (np.float32, "f32")):
