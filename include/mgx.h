@@ -171,6 +171,14 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                            const double* host_ty, const double* host_tz);                               \
     int mgx3d_jacobi_##SFX(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[3],             \
                            const real h[3], real omega, int ncycles);                                   \
+    /* vcycle_tail: the whole VCycle(v1, v2) (N3/MultiGrid3D.cpp:623-647) over levels[0 .. nlev), each  */ \
+    /* at most 17 points per axis (n and h flattened {x0, y0, z0, x1, ...}; v / f HOST arrays of device  */ \
+    /* pointers), in ONE workgroup with every level in LDS; top_zero != 0: v of levels[0] is taken as   */ \
+    /* zeros without being read.  Leaves v of all levels and f of levels 1.. as the launch-per-operator */ \
+    /* cycle does.  _fits: 1 when these levels can run that way ("relax3d.small" = 0 turns it off)      */ \
+    int mgx3d_vcycle_tail_##SFX(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const int* n,   \
+                                const real* h, int v1, int v2, int mode, int top_zero);                 \
+    int mgx3d_vcycle_tail_fits_##SFX(const mgx_ctx* ctx, int nlev, const int* n);                       \
     int mgx3d_diff_stats_##SFX(mgx_ctx* ctx, const real* v, const int n[3], const double* host_tx,      \
                                const double* host_ty, const double* host_tz, double host_out[4]);       \
     /* x-split twins: same operators on arrays whose x-rows are de-interleaved (see below).  An        */ \
@@ -202,6 +210,9 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                              const double* host_ty, const double* host_tz);                             \
     int mgx3dxs_jacobi_##SFX(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[3],           \
                              const real h[3], real omega, int ncycles);                                 \
+    int mgx3dxs_vcycle_tail_##SFX(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const int* n, \
+                                  const real* h, int v1, int v2, int mode, int top_zero);               \
+    int mgx3dxs_vcycle_tail_fits_##SFX(const mgx_ctx* ctx, int nlev, const int* n);                     \
     int mgx3dxs_diff_stats_##SFX(mgx_ctx* ctx, const real* v, const int n[3], const double* host_tx,    \
                                  const double* host_ty, const double* host_tz, double host_out[4]);     \
     /* z-slab forms for the multi-GPU decomposition.  A slab is a local x-split array of consecutive */ \

@@ -565,6 +565,152 @@ __global__ void __launch_bounds__(1024) relax3d_small_kernel(real* __restrict__ 
         if (kind[k] >= 0) v[gidx[k]] = sv[threadIdx.x + k * 1024];
 }
 
+// ------------------------------------------------------------------ the whole cycle below 17^3 in one workgroup
+// Levels up to 17^3 cost one launch of about 5 us per operator (relax, residual+restrict, fill, correct: 5 launches per
+// level and cycle, 20 for the levels 17 ... 3 of the bench hierarchy) although they hold a few thousand points.  Here ONE
+// workgroup keeps v and f of every such level in LDS (93 KB in fp64 + a residual scratch of the top level) and runs
+// MultiGrid3D::VCycle from the top level of the tail down to the coarsest level and back (N3/MultiGrid3D.cpp:623-647):
+// same per-point expressions, same colour order, same operator order -- bit-identical to the launch-per-operator path.
+constexpr int TAIL3_MAXLEV = 6;
+constexpr int TAIL3_PT = (SMALL_MAX * SMALL_MAX * SMALL_MAX + 1023) / 1024;  // points per thread of a 17^3 level
+template <class real>
+struct Tail3 {
+    int nlev;
+    int sx[TAIL3_MAXLEV], sy[TAIL3_MAXLEV], sz[TAIL3_MAXLEV];
+    real* v[TAIL3_MAXLEV];
+    real* f[TAIL3_MAXLEV];
+    real hx[TAIL3_MAXLEV], hy[TAIL3_MAXLEV], hz[TAIL3_MAXLEV];
+};
+
+template <class real>
+__device__ __forceinline__ void tail_relax3(real* sv, const real* sf, int sx, int sxy, const int (&kind)[TAIL3_PT], real hx2, real hy2,
+                                            real hz2, int ncycles) {
+    for (int c = 0; c < 2 * ncycles; c++) {
+        const int colour = c & 1;  // red = 0 first (N3/MultiGrid3D.cpp:515), then black (:544)
+#pragma unroll
+        for (int k = 0; k < TAIL3_PT; k++)
+            if (kind[k] == colour) {
+                const int t = threadIdx.x + k * 1024;
+                sv[t] = relax3d_point<real>(sv[t - 1], sv[t + 1], sv[t - sx], sv[t + sx], sv[t - sxy], sv[t + sxy], sf[t], hx2, hy2, hz2);
+            }
+        __syncthreads();
+    }
+}
+
+template <class real, class L>
+__global__ void __launch_bounds__(1024) cycle3d_tail_kernel(Tail3<real> T, int v1, int v2, int mode, int top_zero) {
+    extern __shared__ __align__(16) unsigned char smem3[];
+    real* base = (real*)smem3;
+    int offv[TAIL3_MAXLEV], offf[TAIL3_MAXLEV];
+    int o = 0;
+#pragma unroll
+    for (int l = 0; l < TAIL3_MAXLEV; l++) {
+        const int n = l < T.nlev ? T.sx[l] * T.sy[l] * T.sz[l] : 0;
+        offv[l] = o;
+        o += n;
+        offf[l] = o;
+        o += n;
+    }
+    real* sr = base + o;  // residual of the level being restricted (as large as the top level)
+    {   // top level of the tail: v as it stands (or the zeroed error of a coarse level, without reading it), f
+        const Geo<L, real> g(T.sx[0], T.sy[0]);
+        const int sx = T.sx[0], sxy = T.sx[0] * T.sy[0], n = sxy * T.sz[0];
+        for (int t = threadIdx.x; t < n; t += 1024) {
+            const int z = t / sxy, y = (t - z * sxy) / sx, x = t - z * sxy - y * sx;
+            const size_t gi = g.row(y, z) + g.pos(x);
+            base[offv[0] + t] = top_zero ? (real)0 : T.v[0][gi];
+            base[offf[0] + t] = T.f[0][gi];
+        }
+    }
+    __syncthreads();
+    const int last = T.nlev - 1;
+    int kind[TAIL3_PT];
+    auto classify = [&](int sx, int sy, int sz) {  // colour of the interior points this thread owns, -1 otherwise
+        const int sxy = sx * sy, n = sxy * sz;
+#pragma unroll
+        for (int k = 0; k < TAIL3_PT; k++) {
+            const int t = threadIdx.x + k * 1024;
+            kind[k] = -1;
+            if (t < n) {
+                const int z = t / sxy, y = (t - z * sxy) / sx, x = t - z * sxy - y * sx;
+                if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1 && z > 0 && z < sz - 1) kind[k] = (x + y + z) & 1;
+            }
+        }
+    };
+    for (int l = 0; l <= last; l++) {  // way down                                            N3/MultiGrid3D.cpp:626-635
+        real* sv = base + offv[l];
+        real* sf = base + offf[l];
+        const int sx = T.sx[l], sy = T.sy[l], sz = T.sz[l], sxy = sx * sy, n = sxy * sz;
+        const real hx2 = T.hx[l] * T.hx[l], hy2 = T.hy[l] * T.hy[l], hz2 = T.hz[l] * T.hz[l];  // :498-500
+        classify(sx, sy, sz);
+        tail_relax3<real>(sv, sf, sx, sxy, kind, hx2, hy2, hz2, v1);  // :626
+        if (l == last) {
+            tail_relax3<real>(sv, sf, sx, sxy, kind, hx2, hy2, hz2, v2);  // :645 on the coarsest level
+            break;
+        }
+#pragma unroll
+        for (int k = 0; k < TAIL3_PT; k++) {  // CalculateResidual (:723), 0 on the boundary (:704-705)
+            const int t = threadIdx.x + k * 1024;
+            if (t < n) {
+                real r = (real)0;
+                if (kind[k] >= 0) {
+                    if (mode == MGX_RESIDUAL_REF_COMPAT)
+                        r = residual3d_point<real, 0>(sv[t - 1], sv[t + 1], sv[t - sx], sv[t + sx], sv[t - sxy], sv[t + sxy], sv[t], sf[t], hx2, hy2, hz2);
+                    else
+                        r = residual3d_point<real, 1>(sv[t - 1], sv[t + 1], sv[t - sx], sv[t + sx], sv[t - sxy], sv[t + sxy], sv[t], sf[t], hx2, hy2, hz2);
+                }
+                sr[t] = r;
+            }
+        }
+        __syncthreads();
+        const int cx = T.sx[l + 1], cy = T.sy[l + 1], cz = T.sz[l + 1], cxy = cx * cy;
+        real* cv = base + offv[l + 1];
+        real* cf = base + offf[l + 1];
+        for (int t = threadIdx.x; t < cxy * cz; t += 1024) {  // Restrict (:122-180), boundary = injection of a zero residual (:113-119)
+            const int pz = t / cxy, py = (t - pz * cxy) / cx, px = t - pz * cxy - py * cx;
+            real out = (real)0;
+            if (px > 0 && px < cx - 1 && py > 0 && py < cy - 1 && pz > 0 && pz < cz - 1) {
+                const real* c = sr + 2 * px + 2 * py * sx + 2 * pz * sxy;
+                out = restrict3d_point<real>([&](int dx, int dy, int dz) { return c[dx + dy * sx + dz * sxy]; });
+            }
+            cf[t] = out;
+            cv[t] = (real)0;  // setToValue(coarse v, 0, true)   :634
+        }
+        __syncthreads();
+    }
+    for (int l = last - 1; l >= 0; l--) {  // way up                                          N3/MultiGrid3D.cpp:638-645
+        real* sv = base + offv[l];
+        real* sf = base + offf[l];
+        const real* c = base + offv[l + 1];
+        const int sx = T.sx[l], sy = T.sy[l], sz = T.sz[l], sxy = sx * sy;
+        const int cx = T.sx[l + 1], cxy = cx * T.sy[l + 1];
+        const real hx2 = T.hx[l] * T.hx[l], hy2 = T.hy[l] * T.hy[l], hz2 = T.hz[l] * T.hz[l];
+        classify(sx, sy, sz);
+#pragma unroll
+        for (int k = 0; k < TAIL3_PT; k++)
+            if (kind[k] >= 0) {  // Interpolate into the error, ApplyCorrection (:216-329, :672)
+                const int t = threadIdx.x + k * 1024;
+                const int z = t / sxy, y = (t - z * sxy) / sx, x = t - z * sxy - y * sx;
+                const real* cc = c + (x >> 1) + (y >> 1) * cx + (z >> 1) * cxy;
+                const real e = interpolate3d_point<real>(x & 1, y & 1, z & 1, [&](int dx, int dy, int dz) { return cc[dx + dy * cx + dz * cxy]; });
+                sv[t] = sv[t] + e;
+            }
+        __syncthreads();
+        tail_relax3<real>(sv, sf, sx, sxy, kind, hx2, hy2, hz2, v2);  // :645
+    }
+    // what the launch-per-operator path leaves behind: v of every level, the restricted residual in f below the top
+    for (int l = 0; l <= last; l++) {
+        const Geo<L, real> g(T.sx[l], T.sy[l]);
+        const int sx = T.sx[l], sxy = T.sx[l] * T.sy[l], n = sxy * T.sz[l];
+        for (int t = threadIdx.x; t < n; t += 1024) {
+            const int z = t / sxy, y = (t - z * sxy) / sx, x = t - z * sxy - y * sx;
+            const size_t gi = g.row(y, z) + g.pos(x);
+            T.v[l][gi] = base[offv[l] + t];
+            if (l > 0) T.f[l][gi] = base[offf[l] + t];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ weighted Jacobi (addition)
 // north_star names weighted Jacobi next to red-black Gauss-Seidel; the reference only has the latter (Jacobi is
 // pseudo-code in the thesis).  One sweep: vout = v + omega * (u - v), u = the Gauss-Seidel value of
@@ -1901,6 +2047,53 @@ int diff_stats3d(mgx_ctx* ctx, const real* v, const int n[3], const double* tx, 
     return MGX_OK;
 }
 
+// levels[0 .. nlev) of a hierarchy (the top level of the tail first), each at most 17 points per axis; n = {sx0, sy0,
+// sz0, sx1, ...}, h likewise; v / f are HOST arrays of device pointers in layout L
+static bool tail3_fits(int nlev, const int* n, size_t elem) {
+    if (!n || nlev < 1 || nlev > TAIL3_MAXLEV) return false;
+    size_t e = (size_t)n[0] * n[1] * n[2];
+    for (int l = 0; l < nlev; l++) {
+        if (n[3 * l] > SMALL_MAX || n[3 * l + 1] > SMALL_MAX || n[3 * l + 2] > SMALL_MAX) return false;
+        e += (size_t)2 * n[3 * l] * n[3 * l + 1] * n[3 * l + 2];
+    }
+    return e * elem <= 150 * 1024;
+}
+
+template <class real, class L>
+int cycle3d_tail(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const int* n, const real* h, int v1, int v2, int mode,
+                 int top_zero) {
+    MGX_REQUIRE(ctx && v && f && n && h, MGX_ERR_INVALID, "vcycle_tail3d: NULL argument");
+    MGX_USE(ctx);
+    MGX_REQUIRE(v1 >= 0 && v2 >= 0, MGX_ERR_INVALID, "vcycle_tail3d: negative sweep count");
+    MGX_REQUIRE(mode == MGX_RESIDUAL_REF_COMPAT || mode == MGX_RESIDUAL_CORRECT, MGX_ERR_INVALID, "vcycle_tail3d: bad mode %d", mode);
+    MGX_REQUIRE(tail3_fits(nlev, n, sizeof(real)), MGX_ERR_SIZE, "vcycle_tail3d: the levels do not fit (at most %d levels of at most %d^3)",
+                TAIL3_MAXLEV, SMALL_MAX);
+    Tail3<real> T;
+    memset(&T, 0, sizeof T);
+    T.nlev = nlev;
+    size_t elems = (size_t)n[0] * n[1] * n[2];
+    for (int l = 0; l < nlev; l++) {
+        const int* nl = n + 3 * l;
+        int st = check_n3(nl, "vcycle_tail3d");
+        if (st) return st;
+        if (l > 0) {
+            st = check_coarse3(n + 3 * (l - 1), nl, "vcycle_tail3d");
+            if (st) return st;
+        }
+        MGX_REQUIRE(v[l] && f[l], MGX_ERR_INVALID, "vcycle_tail3d: NULL level array");
+        T.sx[l] = nl[0]; T.sy[l] = nl[1]; T.sz[l] = nl[2];
+        T.v[l] = v[l]; T.f[l] = f[l];
+        T.hx[l] = h[3 * l]; T.hy[l] = h[3 * l + 1]; T.hz[l] = h[3 * l + 2];
+        elems += (size_t)2 * nl[0] * nl[1] * nl[2];
+    }
+    const size_t lds = elems * sizeof(real);
+    if (lds > 64 * 1024)
+        MGX_HIP(hipFuncSetAttribute((const void*)cycle3d_tail_kernel<real, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((cycle3d_tail_kernel<real, L>), dim3(1), dim3(1024), lds, ctx->compute, T, v1, v2, mode, top_zero);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
 template <class real>
 int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
     MGX_REQUIRE(ctx && (x || !count) && host_sumsq, MGX_ERR_INVALID, "norm2: NULL argument");
@@ -1962,6 +2155,13 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
     int PFX##jacobi_##SFX(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[3], const real h[3],      \
                           real omega, int ncycles) {                                                             \
         return mgx::jacobi3d<real, L>(ctx, v, tmp, f, n, h, omega, ncycles);                                     \
+    }                                                                                                            \
+    int PFX##vcycle_tail_##SFX(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const int* n,             \
+                               const real* h, int v1, int v2, int mode, int top_zero) {                          \
+        return mgx::cycle3d_tail<real, L>(ctx, nlev, v, f, n, h, v1, v2, mode, top_zero);                        \
+    }                                                                                                            \
+    int PFX##vcycle_tail_fits_##SFX(const mgx_ctx* ctx, int nlev, const int* n) {                                \
+        return ctx && ctx->relax_small && mgx::tail3_fits(nlev, n, sizeof(real));                                \
     }                                                                                                            \
     int PFX##diff_stats_##SFX(mgx_ctx* ctx, const real* v, const int n[3], const double* host_tx,                \
                               const double* host_ty, const double* host_tz, double host_out[4]) {                \

@@ -291,6 +291,42 @@ def test_3d_cycles_f64_vs_oracle(ctx, n, nlev, mode, layout):
         mg.close()
 
 
+@pytest.mark.parametrize("small", [1, 0])
+@pytest.mark.parametrize("layout", ["natural", "xsplit"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_3d_one_workgroup_tail_of_the_cycle(ctx, small, layout, dtype):
+    """levels of at most 17^3: the rest of the V-cycle (way down and way up) in ONE launch with every level in LDS
+    ("relax3d.small" = 1, the default) == one launch per operator ("relax3d.small" = 0) == oracle; hierarchies that end
+    in the tail, start inside it, are anisotropic, stop early (numGrids), use 0 sweeps, both residual modes"""
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    cases = [((33, 33, 33), 0, 2, 2, P.REF_COMPAT), ((65, 33, 17), 0, 1, 3, P.CORRECT), ((17, 17, 17), 0, 2, 2, P.REF_COMPAT),
+             ((9, 17, 9), 0, 0, 2, P.CORRECT), ((5, 5, 5), 0, 2, 0, P.REF_COMPAT), ((3, 3, 3), 0, 3, 1, P.REF_COMPAT),
+             ((33, 33, 33), 2, 2, 2, P.REF_COMPAT), ((33, 17, 33), 3, 1, 1, P.CORRECT), ((17, 17, 17), 1, 2, 2, P.REF_COMPAT)]
+    ctx.set_param("relax3d.small", small)
+    try:
+        for n3, nlev, v1, v2, mode in cases:
+            rng = np.random.default_rng(sum(n3) + nlev)
+            v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+            f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+            mg = P.MultiGrid3D(ctx, n3, rg, dtype, nlevels=nlev, residual_mode=mode, layout=layout)
+            mg.upload_v(0, v)
+            mg.upload_f(0, f)
+            mg.VCycle(0, v1, v2)
+            mg.VCycle(0, v1, v2)
+            want = O.cycle3d(n3, rg, nlevels=nlev, mode=0, v1=v1, v2=v2, reps=2, v=v, f=f, residual_mode=mode, dtype=dtype)
+            assert bits_equal(mg.download_v(0), want), (n3, nlev, v1, v2, mode)
+            mg.close()
+            mg = P.MultiGrid3D(ctx, n3, rg, dtype, nlevels=nlev, residual_mode=mode, layout=layout)
+            mg.upload_v(0, v)
+            mg.upload_f(0, f)
+            mg.FullMultiGridVCycle(0, 2, v1, v2)
+            want = O.cycle3d(n3, rg, nlevels=nlev, mode=1, v0=2, v1=v1, v2=v2, v=v, f=f, residual_mode=mode, dtype=dtype)
+            assert bits_equal(mg.download_v(0), want), ("fmg", n3, nlev, v1, v2, mode)
+            mg.close()
+    finally:
+        ctx.set_param("relax3d.small", 1)
+
+
 def test_3d_baseline_config2_257_f64(ctx):
     """BASELINE.json configs[2]: 3D Poisson 256^3 (257 points/axis), 6-level V-cycle, fp64."""
     mg = P.MultiGrid3D(ctx, [257] * 3, R3, np.float64, nlevels=6)
