@@ -246,6 +246,13 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx3dxs_interpolate_correct_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff,        \
                                                const real* coarse_v, const int cn[3], int czoff,        \
                                                int pzbeg, int pzend);                                   \
+    /* interpolate_correct_relax: v += Interpolate(coarse_v) on the interior, then ncycles >= 1 sweeps   */ \
+    /* (N3/MultiGrid3D.cpp:638-645 in one call).  On large levels the first red pass reads the black     */ \
+    /* points THROUGH the correction instead of the correction being stored first ("relax3d.corr_fuse"  */ \
+    /* = 0 turns that off); the result is bit-identical to interpolate_correct followed by relax.       */ \
+    int mgx3dxs_interpolate_correct_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3],   \
+                                                const real h[3], const real* coarse_v, const int cn[3], \
+                                                int ncycles);                                           \
     /* _colour forms: only the points with (x + y + z_global) % 2 == colour are corrected (-1 = all).  */ \
     /* The cycle passes colour 1 (black) when red-black sweeps follow: the red pass rewrites every red */ \
     /* interior point from black neighbours alone, so a corrected red value is never read.            */ \

@@ -366,13 +366,41 @@ __global__ void __launch_bounds__(64 * WX * WY)
 //   5. waits for what it issued in 1 (explicit s_waitcnt vmcnt(0)) and renames the register sets.
 // Loads and stores therefore have the whole step (LDS traffic, ~40 fp64 operations per point, the barrier) to
 // complete, and a wave has memory requests in flight all the time instead of only while it waits for them.
-template <class real, int WX, int WY, int R, bool FNT = false>
+//
+// VAR = 2 ("CORR"): the pass reads the other colour THROUGH the coarse-grid correction -- every own-column value of the
+// other colour that enters the registers gets e = Interpolate(coarse)(x, y, z) added if it is an interior point: exactly
+// what Interpolate + ApplyCorrection (N3/MultiGrid3D.cpp:638-642) would have stored there.  The first red pass of the
+// post-smoothing then needs no corrected array: corrected red values are never read (the red pass rewrites every red
+// interior point from black neighbours alone) and corrected black values are only read by THIS pass (the black pass that
+// follows rewrites every black interior point from red).  The coarse values under the tile (WY R / 2 + 1 rows x 64 WX + 1
+// columns per coarse plane) are staged in LDS by the whole workgroup, one coarse plane every other step, in a ring of
+// three planes (a wave is at most one step ahead of another: while planes p, p + 1 are read, only p + 2 can be written).
+// A plane is requested three steps before it is first read, by the last loads of its step, which stay in flight over the
+// step's end (the explicit wait leaves them outstanding; waited for in the requesting step they cost 59 us per pass);
+// it is stored at the end of the next step, and the correction of an arriving entry is formed before the step's barrier,
+// while the entry is still on its way: nothing is added between the arrival of a step's loads and the issue of the next
+// ones.  (Holding the coarse values in registers instead costs 16 VGPRs, which spills, and a spill reload inside the loop
+// waits -- vmcnt is in order -- for the prefetches issued before it: 2.5 x slower.)
+template <class real>
+__device__ __forceinline__ real interp_xs_at(const real* __restrict__ coarse, int CH, int CP, size_t CPL, int x, int y, int z) {
+    const real* c = coarse + (size_t)(y >> 1) * CP + (size_t)(z >> 1) * CPL;
+    const int gx = x >> 1;
+    return interpolate3d_point<real>(x & 1, y & 1, z & 1,
+                                     [&](int dx, int dy, int dz) { return c[XSplit::pos(gx + dx, CH) + dy * CP + (size_t)dz * CPL]; });
+}
+
+template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0>
 __global__ void __launch_bounds__(64 * WX * WY)
     relax3d_xs_pipe_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                            int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
-                           int xcd_mode) {
+                           int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0) {
+    constexpr bool CORR = VAR == 2;
+    static_assert(!CORR || R == 2, "the correcting variant is written for 2 rows per lane");
+    static_assert(!CORR || (WX * WY >= WY * R / 2 + 2 && WY > 1), "one wave per coarse row under the tile and its rim");
+    constexpr int KR = WY * R / 2 + 1, KC = 64 * WX + 2;  // coarse rows / columns staged per plane (column 0: left of the tile, unused)
     __shared__ real ey[2][WY][WX][2][64];
     __shared__ real ex[2][WY][WX][2][R];
+    __shared__ real sK[CORR ? 3 : 1][CORR ? KR : 1][CORR ? KC : 1];
     const Geo<XSplit, real> g(sx, sy);
     const int H = g.H;
     const int M = (sx + 1) >> 1;
@@ -410,6 +438,68 @@ __global__ void __launch_bounds__(64 * WX * WY)
     int q = (colour + y0 + z0) & 1;
     real cp[R], cc[R], cu[R], cn[R], fc[R], fn[R], xc[R], xn[R], oc[R], op[R];
     real Nc = 0, Sc = 0, Nn = 0, Sn = 0;
+    // CORR: coarse geometry; this thread's share of the staging of one coarse plane (wave w < KR: row w of the staged
+    // rows, columns lane, lane + 64, ... and, lanes 0 and 1, the last two); where this lane's own coarse cell sits in the
+    // staged tile (column 0 is the coarse column left of the tile)
+    const Geo<XSplit, real> gcs(CORR ? cx : 3, CORR ? cy : 3);
+    const int CH = gcs.H, CP = gcs.P;
+    const size_t CPL = gcs.PL;
+    const int cy0t = CORR ? (by * WY * R) / 2 : 0, cx0t = bx * WX * 64;  // first coarse row / column under the tile
+    int kg[WX + 1];  // element offsets (inside a coarse plane) of the entries this thread stages
+    const bool kload = CORR && w < KR, klast = kload && lane < 2;
+#pragma unroll
+    for (int a = 0; a <= WX; a++)
+        kg[a] = CORR ? min(cy0t + w, cy - 1) * CP + XSplit::pos(min(max(cx0t - 1 + lane + 64 * a, 0), cx - 1), CH) : 0;
+    real kt[WX + 1];  // a coarse plane on its way into LDS
+#pragma unroll
+    for (int a = 0; a <= WX; a++) kt[a] = 0;
+    const int kmy = wy * (R / 2) * KC + wx * 64 + lane + 1;  // sK offset of coarse cell (column j, row (y0 - 1) / 2) inside a plane slot
+    // The values a workgroup takes from memory besides its own columns (the rows just above / below its tile, the pairs
+    // left / right of it) would each need an interpolation of their own in every step -- measured: +100 us per pass at
+    // 513^3, the edge waves hold up the whole workgroup at the barrier.  Instead the black points of the coarse cells those
+    // values belong to (the set P: cell rows py % (WY R / 2) == 0, cell columns i > 0 with i % (64 WX) in {0, 64 WX - 1};
+    // about 1/8 of the cells) are corrected IN PLACE by correct_pset3d_xs_kernel before this pass; own entries in P are
+    // taken as they are.
+    bool own[R];  // does row r's own entry get the correction on the fly?
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const bool inP = (wy == 0 && r == 0) || (wy == WY - 1 && r == R - 1) || (j > 0 && j % (64 * WX) == 0) || (j % (64 * WX) == 64 * WX - 1);
+        own[r] = CORR && lane_on && !inP && y0 + r <= sy - 2;
+    }
+    // request coarse plane `plane` (kt), store what was requested into its ring slot
+#define MGX_K_REQUEST(plane)                                                                    \
+    do {                                                                                        \
+        if (kload) {                                                                            \
+            const real* c_ = coarse + (size_t)(plane) * CPL;                                    \
+            _Pragma("unroll") for (int a = 0; a < WX; a++) kt[a] = c_[kg[a]];                   \
+            if (klast) kt[WX] = c_[kg[WX]];                                                     \
+        }                                                                                       \
+    } while (0)
+#define MGX_K_STORE(plane)                                                                      \
+    do {                                                                                        \
+        if (kload) {                                                                            \
+            real* d_ = &sK[(plane) % 3][w][lane];                                               \
+            _Pragma("unroll") for (int a = 0; a < WX; a++) d_[64 * a] = kt[a];                  \
+            if (klast) d_[64 * WX] = kt[WX];                                                    \
+        }                                                                                       \
+    } while (0)
+    // the corrections e0 / e1 of this lane's entries of row 0 / row 1 at plane zz (x = 2j + px0 in row 0, the other parity in
+    // row 1) from the staged planes zz >> 1 (k0_) and (zz >> 1) + 1 (k1_).  Row 0 (odd y) lies between two coarse rows, row 1
+    // on the second of them, so the parity class of both entries follows from (px0, zz & 1): ONE uniform branch, and in
+    // every case interpolate3d_point with literal class arguments (the reference's association, N3/MultiGrid3D.cpp:216-329)
+#define MGX_CORR_PAIR(px0, zz, e0, e1)                                                                              \
+    do {                                                                                                            \
+        const real* k0_ = &sK[0][0][0] + ((zz) >> 1) % 3 * (KR * KC) + kmy;                                         \
+        const real* k1_ = &sK[0][0][0] + (((zz) >> 1) + 1) % 3 * (KR * KC) + kmy;                                   \
+        auto g0_ = [&](int dx, int dy, int dz) { return (dz ? k1_ : k0_)[dy * KC + dx]; };                          \
+        auto g1_ = [&](int dx, int dy, int dz) { return (dz ? k1_ : k0_)[KC + dy * KC + dx]; };                     \
+        switch ((px0) * 2 + ((zz) & 1)) {                                                                           \
+            case 0: e0 = interpolate3d_point<real>(0, 1, 0, g0_); e1 = interpolate3d_point<real>(1, 0, 0, g1_); break; \
+            case 1: e0 = interpolate3d_point<real>(0, 1, 1, g0_); e1 = interpolate3d_point<real>(1, 0, 1, g1_); break; \
+            case 2: e0 = interpolate3d_point<real>(1, 1, 0, g0_); e1 = interpolate3d_point<real>(0, 0, 0, g1_); break; \
+            default: e0 = interpolate3d_point<real>(1, 1, 1, g0_); e1 = interpolate3d_point<real>(0, 0, 1, g1_); break; \
+        }                                                                                                           \
+    } while (0)
 
     // everything that comes from memory besides the column itself, for the plane at offset dz from pv, row parity qq.
     // rim-right lanes need index j+1 of half 0 in q_r = 1 rows, rim-left lanes index j-1 of half 1 in q_r = 0 rows
@@ -458,6 +548,26 @@ __global__ void __launch_bounds__(64 * WX * WY)
         op[r] = 0;
     }
     MGX_LOAD_RIM(0, q, xc, Nc, Sc);
+    if constexpr (CORR) {
+        // own entries of the planes z0-1, z0, z0+1: the correction straight from the coarse array, once per run of planes
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (own[r]) {
+                const int qr = q ^ (r & 1), y = y0 + r;
+                if (z0 - 1 >= 1 && (qr | j)) cp[r] = cp[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + qr, y, z0 - 1);
+                if ((1 - qr) | j) cc[r] = cc[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + 1 - qr, y, z0);
+                if (z0 + 1 <= szg - 2 && (qr | j)) cu[r] = cu[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + qr, y, z0 + 1);
+            }
+        // the coarse planes under the arrivals of the first three steps (the loop's requests start with the fourth)
+        MGX_K_REQUEST((z0 + 2) >> 1);
+        MGX_K_STORE((z0 + 2) >> 1);
+        MGX_K_REQUEST(min(((z0 + 2) >> 1) + 1, (szg - 1) >> 1));
+        MGX_K_STORE(((z0 + 2) >> 1) + 1);
+        if (z0 & 1) {
+            MGX_K_REQUEST(min(((z0 + 2) >> 1) + 2, (szg - 1) >> 1));
+            MGX_K_STORE(((z0 + 2) >> 1) + 2);
+        }
+    }
     publish(z0 & 1, cc);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -472,6 +582,13 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 fn[r] = (FNT ? __builtin_nontemporal_load(&pf[roff[r] + sxy + qn * H + j]) : pf[roff[r] + sxy + qn * H + j]);
             }
             MGX_LOAD_RIM(1, q ^ 1, xn, Nn, Sn);
+            if constexpr (CORR) {
+                // the correction of the plane that arrives in step s is formed in step s itself, BEFORE its barrier, from the
+                // coarse planes (s + 2) >> 1 and, for odd s, (s + 3) / 2: that one is requested in step s - 3 (these are
+                // the LAST loads of the step: they stay in flight over the step's end), stored at the end of step s - 2
+                // and so visible from the barrier of step s - 1 on
+                if (!(z & 1) && z + 4 < z1) MGX_K_REQUEST(min((z >> 1) + 3, (szg - 1) >> 1));
+            }
             publish((z + 1) & 1, cu);
         }
         const int slot = z & 1;
@@ -496,16 +613,40 @@ __global__ void __launch_bounds__(64 * WX * WY)
             const real S = r == R - 1 ? Sedge : cc[r + 1];
             oc[r] = relax3d_point<real>(W, E, N, S, cp[r], cu[r], fc[r], hx2, hy2, hz2);
         }
+        real en[R];   // CORR: the correction of the entries that are on their way (plane z + 2, x = 2j + qn) ...
+        bool dc[R];   // ... if they get one
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            en[r] = 0;
+            dc[r] = false;
+        }
+        if constexpr (CORR) {
+            if (more) {
+                MGX_CORR_PAIR(q ^ 1, z + 2, en[0], en[1]);  // all lanes: the staged tile covers every lane's cell
+#pragma unroll
+                for (int r = 0; r < R; r++) dc[r] = own[r] && z + 2 <= szg - 2 && ((q ^ 1 ^ (r & 1)) | j);
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this step's prefetch and stores have had the whole step
+        if (CORR && kload && more && !(z & 1) && z + 4 < z1) {
+            // the staging loads issued last in this step may stay in flight (loads return in order: at most WX + 1
+            // outstanding operations means everything issued before them has arrived); they are stored a step later
+            if constexpr (WX == 2) __builtin_amdgcn_s_waitcnt(0x0F73);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this step's prefetch and stores have had the whole step
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) {
             cp[r] = cc[r];
             cc[r] = cu[r];
-            cu[r] = cn[r];
+            cu[r] = dc[r] ? cn[r] + en[r] : cn[r];
             fc[r] = fn[r];
             xc[r] = xn[r];
             op[r] = oc[r];
+        }
+        if constexpr (CORR) {
+            if ((z & 1) && z > z0 && z + 3 < z1) MGX_K_STORE(((z - 1) >> 1) + 3);  // requested in step z - 1
         }
         Nc = Nn;
         Sc = Sn;
@@ -516,6 +657,9 @@ __global__ void __launch_bounds__(64 * WX * WY)
     }
     store_plane(-1, q ^ 1, op);  // the last plane
 #undef MGX_LOAD_RIM
+#undef MGX_K_REQUEST
+#undef MGX_K_STORE
+#undef MGX_CORR_PAIR
 }
 
 // ------------------------------------------------------------------ relax, whole small level in one workgroup
@@ -861,16 +1005,11 @@ __global__ void __launch_bounds__(256) interpolate3d_kernel(real* __restrict__ f
 // COLOUR >= 0: only the fine points with (x + y + z) % 2 == COLOUR are written (the half-row of that parity in
 // every row).  The cycle uses COLOUR = 1 when a red-black sweep follows: the red pass overwrites every red interior
 // point from black neighbours only, so a corrected red value would never be read.
-template <class real, bool ADD, int COLOUR = -1>
-__global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict__ fine, int fx, int fy, int fzoff,
-                                                               const real* __restrict__ coarse, int cx, int cy, int czoff,
-                                                               int pzbeg) {
-    const Geo<XSplit, real> gf(fx, fy), gc(cx, cy);
+template <class real, bool ADD, int COLOUR>
+__device__ __forceinline__ void interp_cell_xs(real* __restrict__ fine, const Geo<XSplit, real>& gf, int fzoff,
+                                               const real* __restrict__ coarse, const Geo<XSplit, real>& gc, int czoff, int i, int py,
+                                               int pz) {
     const int FH = gf.H, CH = gc.H;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    const int py = blockIdx.y * blockDim.y + threadIdx.y;
-    const int pz = pzbeg + blockIdx.z;
-    if (i >= ((fx + 1) >> 1) - 1 || py >= cy - 1) return;  // fine x = 2i+1 <= fx-2, fine y = 2py+1 <= fy-2
     const size_t cxy = gc.PL, fxy = gf.PL;
     real c[2][2][2];
 #pragma unroll
@@ -900,6 +1039,42 @@ __global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict_
             }
         }
     }
+}
+
+template <class real, bool ADD, int COLOUR = -1>
+__global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict__ fine, int fx, int fy, int fzoff,
+                                                               const real* __restrict__ coarse, int cx, int cy, int czoff,
+                                                               int pzbeg) {
+    const Geo<XSplit, real> gf(fx, fy), gc(cx, cy);
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int py = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pz = pzbeg + blockIdx.z;
+    if (i >= ((fx + 1) >> 1) - 1 || py >= cy - 1) return;  // fine x = 2i+1 <= fx-2, fine y = 2py+1 <= fy-2
+    interp_cell_xs<real, ADD, COLOUR>(fine, gf, fzoff, coarse, gc, czoff, i, py, pz);
+}
+
+// The set P of relax3d_xs_pipe_kernel<.., VAR = 2>: black points of the coarse cells (i, py, pz) with py % PH == 0 (part 0:
+// the two fine rows a workgroup tile of the correcting pass sees just outside itself and, from the neighbouring tile's
+// point of view, its own first / last row) or i % PW in {0, PW - 1}, i > 0 (part 1: the pairs next to a tile's left /
+// right edge; cells of part 0 are skipped there) get v += Interpolate(coarse) in place before the pass runs.
+template <class real>
+__global__ void __launch_bounds__(256) correct_pset3d_xs_kernel(real* __restrict__ fine, int fx, int fy, const real* __restrict__ coarse,
+                                                                int cx, int cy, int PW, int PH, int part) {
+    const Geo<XSplit, real> gf(fx, fy), gc(cx, cy);
+    const int M = (fx + 1) >> 1;
+    const int pz = blockIdx.z;
+    int i, py;
+    if (part == 0) {
+        i = blockIdx.x * 64 + threadIdx.x;
+        py = (blockIdx.y * blockDim.y + threadIdx.y) * PH;
+    } else {
+        const int c = blockIdx.x;  // column group c >> 1 (1, 2, ...), its pair PW g - 1 (c even) or PW g (c odd)
+        i = ((c >> 1) + 1) * PW - 1 + (c & 1);
+        py = blockIdx.y * 256 + threadIdx.y * 64 + threadIdx.x;
+        if (py % PH == 0) return;
+    }
+    if (i >= M - 1 || py >= cy - 1) return;
+    interp_cell_xs<real, true, 1>(fine, gf, 0, coarse, gc, 0, i, py, pz);
 }
 
 template <class real, class L>
@@ -2000,6 +2175,64 @@ int interpolate_correct3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff,
     return MGX_OK;
 }
 
+// v += Interpolate(coarse_v) on the interior, then `ncycles` >= 1 red-black sweeps (N3/MultiGrid3D.cpp:638-645), x-split
+// layout.  On levels wide enough for the pipelined smoother most of the correction never goes through memory: the set P
+// (the cells on the edges of the smoother's workgroup tiles, about 1/8 of the black points) is corrected in place, the
+// first red pass reads every other black value through the correction (relax3d_xs_pipe_kernel, VAR = 2), and the black
+// pass that follows recomputes all black interior points from red.  Elsewhere: the black points are corrected in place,
+// then the sweeps.  Both give the bits of interpolate_correct + relax.
+template <class real>
+int interpolate_correct_relax3d_xs(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], const real* coarse_v,
+                                   const int cn[3], int ncycles) {
+    MGX_REQUIRE(ctx && v && f && h && coarse_v, MGX_ERR_INVALID, "interpolate_correct_relax3d: NULL argument");
+    MGX_USE(ctx);
+    int st = check_n3(n, "interpolate_correct_relax3d");
+    if (st) return st;
+    st = check_coarse3(n, cn, "interpolate_correct_relax3d");
+    if (st) return st;
+    MGX_REQUIRE(ncycles >= 1, MGX_ERR_INVALID, "interpolate_correct_relax3d: ncycles = %d < 1 (use interpolate_correct)", ncycles);
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // :498-500
+    const int sx = n[0], sy = n[1], sz = n[2], M = (sx + 1) / 2, zb = 1, ze = sz - 1;
+    const bool small = sx <= SMALL_MAX && sy <= SMALL_MAX && sz <= SMALL_MAX && ctx->relax_small;
+    const bool fused = ctx->corr_fuse && !small && ctx->relax_lds < 0 && M - 1 >= 128 && sy - 2 >= 64 && ze - zb >= 8;
+    if (!fused) {
+        st = interpolate_correct3d_slab<real>(ctx, v, n, 0, coarse_v, cn, 0, 0, cn[2] - 1, 1);
+        if (st) return st;
+        return relax3d<real, XSplit>(ctx, v, f, n, h, ncycles);
+    }
+    constexpr int PW = 128, PH = 8;  // the tile of relax3d_xs_pipe_kernel<real, 2, 8, 2>: 128 pairs x 16 rows
+    const int nk = (cn[1] - 2) / PH + 1;
+    hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ceil_div(M - 1, 64), ceil_div(nk, 4), cn[2] - 1), blk(), 0, ctx->compute, v,
+                       sx, sy, coarse_v, cn[0], cn[1], PW, PH, 0);
+    const int ncol = 2 * ((M - 1) / PW);
+    if (ncol > 0)
+        hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ncol, ceil_div(cn[1] - 1, 256), cn[2] - 1), blk(), 0, ctx->compute, v, sx,
+                           sy, coarse_v, cn[0], cn[1], PW, PH, 1);
+    // the first red pass through the correction: one resident round of 16-wave workgroups as in relax3d_xs_pass_lds
+    int zchunk = ctx->relax_zchunk;
+    if (zchunk <= 0) {
+        const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, 16);
+        const int target = ctx->num_cus * (sizeof(real) == 4 ? 8 : 1);
+        const int nchunks = max(1, (target + tiles / 2) / tiles);
+        zchunk = max(8, ceil_div(ze - zb, nchunks));
+    }
+    const int gx = ceil_div(M - 1, 128), gy = ceil_div(sy - 2, 16), gz = ceil_div(ze - zb, zchunk);
+    const dim3 grid((unsigned)gx * gy * gz), block(64, 16, 1);
+    const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
+    const bool fnt = (size_t)sx * sy * (size_t)(ze - zb) * sizeof(real) > ((size_t)256 << 20);
+    snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,2,8,2,%s,2>", sizeof(real) == 8 ? "double" : "float",
+             fnt ? "true" : "false");
+    if (fnt)
+        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 8, 2, true, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
+                           hx2, hy2, hz2, 0, zchunk, gx, gy, xcd, coarse_v, cn[0], cn[1], sz);
+    else
+        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 8, 2, false, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
+                           hx2, hy2, hz2, 0, zchunk, gx, gy, xcd, coarse_v, cn[0], cn[1], sz);
+    for (int s = 1; s < 2 * ncycles; s++) relax3d_xs_pass<real>(ctx, v, f, sx, sy, zb, ze, hx2, hy2, hz2, s & 1);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
 template <class real, class L>
 int jacobi3d(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[3], const real h[3], real omega, int ncycles) {
     MGX_REQUIRE(ctx && v && tmp && f && h, MGX_ERR_INVALID, "jacobi3d: NULL argument");
@@ -2211,6 +2444,11 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
         return mgx::interpolate_correct3d_slab<real>(ctx, v, n, fzoff, coarse_v, cn, czoff, pzbeg, pzend,        \
                                                      colour);                                                    \
     }                                                                                                            \
+    int mgx3dxs_interpolate_correct_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3],            \
+                                                const real h[3], const real* coarse_v, const int cn[3],          \
+                                                int ncycles) {                                                   \
+        return mgx::interpolate_correct_relax3d_xs<real>(ctx, v, f, n, h, coarse_v, cn, ncycles);                \
+    }                                                                                                            \
     int mgx3dxs_interpolate_correct_colour_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,    \
                                                  const int cn[3], int colour) {                                  \
         return mgx::interpolate_correct3d_slab<real>(ctx, v, n, 0, coarse_v, cn, 0, 0, cn ? cn[2] - 1 : 0,       \
@@ -2280,6 +2518,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "residual_restrict3d.pzchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "residual_restrict3d.pzchunk must be >= 0 (0 = automatic)");
         ctx->rr_pzchunk = value;
+    } else if (!strcmp(name, "relax3d.corr_fuse")) {
+        ctx->corr_fuse = value ? 1 : 0;  // interpolate_correct_relax: first red pass reads the correction on the fly (1) or in-place correction first (0)
     } else if (!strcmp(name, "cycle2d.tile")) {
         MGX_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64, MGX_ERR_INVALID, "cycle2d.tile must be 0 (automatic), 16, 32 or 64");
         ctx->cyc2_tile = value;

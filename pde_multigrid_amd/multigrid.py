@@ -276,6 +276,15 @@ class _Ops3D(_Ops):
         cn = coarse_size(n)
         return self._run(ctx, [v, coarse], lambda a, c: fn(ctx._h, a, _ip(n), c, _ip(cn), C.c_int(colour)), 0, _shape(n), dtype)
 
+    def interpolate_correct_relax(self, ctx, v, f, n, rng, coarse, ncycles, dtype=None):
+        """x-split only: v += Interpolate(coarse) on the interior, then ncycles >= 1 red-black sweeps, in one call"""
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("interpolate_correct_relax", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        cn = coarse_size(n)
+        return self._run(ctx, [v, f, coarse], lambda a, b, c: fn(ctx._h, a, b, _ip(n), h, c, _ip(cn), C.c_int(ncycles)), 0, _shape(n),
+                         dtype)
+
     def jacobi(self, ctx, v, f, n, rng, omega, ncycles, dtype=None):
         dtype = dtype or v.dtype
         fn, ct = self._fn("jacobi", dtype)

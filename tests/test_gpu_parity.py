@@ -228,6 +228,34 @@ def test_3d_xsplit_interpolate_correct_one_colour(ctx, dtype, n3):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n3", [(257, 129, 33), (513, 129, 17), (257, 257, 17), (1025, 129, 17), (257, 65, 9), (513, 513, 33), (33, 17, 65),
+                                (9, 9, 9), (129, 129, 33)])
+def test_3d_xsplit_interpolate_correct_relax_fused(ctx, dtype, n3):
+    """mgx3dxs_interpolate_correct_relax == Relax(ApplyCorrection(Interpolate)) (N3/MultiGrid3D.cpp:638-645).  On wide
+    levels the first red pass reads the black points through the correction (values of tile-edge cells are corrected in
+    place beforehand, everything else on the fly from coarse values held in registers); random data, so a correction
+    that is missing, doubled or taken from the wrong coarse cell anywhere shows; all run lengths of the plane march"""
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(sum(n3))
+    cn = P.coarse_size(n3)
+    v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    c = rng.uniform(-1, 1, O.shape(cn)).astype(dtype)
+    corrected = O.correct3d(n3, v, O.interpolate3d(n3, np.zeros(O.shape(n3), dtype), c, dtype=dtype), dtype=dtype)
+    try:
+        for fuse in (1, 0):
+            ctx.set_param("relax3d.corr_fuse", fuse)
+            for zchunk in (0, 3, 8, 64):
+                ctx.set_param("relax3d.zchunk", zchunk)
+                for k in (1, 2):
+                    want = O.relax3d(n3, rg, corrected, f, k, dtype=dtype)
+                    assert bits_equal(P.ops3dxs.interpolate_correct_relax(ctx, v, f, n3, rg, c, k), want), (fuse, zchunk, k)
+    finally:
+        ctx.set_param("relax3d.corr_fuse", 1)
+        ctx.set_param("relax3d.zchunk", 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n3", [(257, 129, 33), (513, 129, 17), (257, 257, 12 + 5), (1025, 129, 9)])
 def test_3d_xsplit_relax_default_kernel_choice_large_rows(ctx, dtype, n3):
     """default parameters on levels wide enough for the automatic choice of the pipelined LDS-exchange smoother"""
