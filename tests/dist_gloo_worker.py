@@ -173,6 +173,14 @@ def _rank_main(rank, world, port, n, v1, v2, cycles, min_planes, mode, out_path,
         vcycle(0)
     p = plans[0]
     np.save(out_path % rank, v[0][p.zlo:p.zhi])
+    # mgDistMultiGrid3D_ResidualNorm: squared residual over the owned interior planes (their neighbours zlo-1 / zhi are
+    # fresh ghosts after the last exchange), one all-reduce (sum) of one double
+    poison(v[0], p)
+    poison(f[0], p)
+    r = O.residual3d([n] * 3, R3, v[0], f[0], mode, dtype)
+    mine = torch.tensor([float(np.sum(r[p.ubeg:p.uend] ** 2))], dtype=torch.float64)
+    dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+    np.save((out_path % rank) + ".norm.npy", np.array([np.sqrt(mine.item())]))
     dist.barrier()
     dist.destroy_process_group()
 

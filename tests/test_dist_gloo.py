@@ -49,6 +49,13 @@ def test_slab_plan_world2_matches_single_domain(tmp_path, n, min_planes, mode):
     assert got.shape == want.shape
     assert not np.isnan(got).any()
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    # the distributed residual norm (slab sums + all-reduce of one double): same value on both ranks, equal to the norm of
+    # the single-domain residual up to the summation order (an addition without a reference: parity unpinned)
+    norms = [float(np.load((out % r) + ".norm.npy")[0]) for r in range(world)]
+    f0 = O.init3d([n] * 3, R3, 0, np.float64)[1]
+    ref = float(np.sqrt(np.sum(O.residual3d([n] * 3, R3, want, f0, mode, np.float64) ** 2)))
+    assert norms[0] == norms[1] and np.isfinite(norms[0])
+    assert abs(norms[0] - ref) <= 1e-12 * ref
 
 
 @pytest.mark.parametrize("n,min_planes,mode", [(33, 4, O.REF_COMPAT), (33, 2, O.CORRECT)])
@@ -88,3 +95,28 @@ def test_plan_invariants():
                     assert 1 <= p.ubeg <= p.uend <= size - 1
                 size = (size - 1) // 2 + 1
             assert 0 <= nd < ng or world == 1
+
+
+def test_bench_checksum_of_slabs_adds_up():
+    """bench.py's result check at N > 1: every rank sums the planes it owns with the word index of the whole array and
+    rank 0 adds the parts mod 2^64 -- equal to the checksum of the assembled array (and to oracle/gen_known_f64.py's)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    spec = importlib.util.spec_from_file_location("gen_known", os.path.join(root, "oracle", "gen_known_f64.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rng = np.random.default_rng(0)
+    for dtype in (np.float64, np.float32):
+        a = rng.uniform(-1, 1, (33, 17, 9)).astype(dtype)
+        whole = bench.checksum(a)
+        assert ("%016x" % whole[0], "%016x" % whole[1]) == gen.checksum64(a)
+        for world in (2, 4, 8):
+            s1 = s2 = 0
+            for r in range(world):
+                pl = P.slab_plan(33, r, world)
+                q1, q2 = bench.checksum(a[pl.zlo:pl.zhi], pl.zlo * 17 * 9)
+                s1, s2 = (s1 + q1) & ((1 << 64) - 1), (s2 + q2) & ((1 << 64) - 1)
+            assert (s1, s2) == whole
