@@ -187,6 +187,11 @@ def main():
     wbytes = np.dtype(dtype).itemsize
     n = args.n or (513 if world == 1 else 1025)
     ctx = P.Context(local_rank)
+    # A/B runs: MGX_BENCH_PARAMS="name=value,..." sets context parameters (speed knobs only: results never change) and is
+    # reported in config.params
+    params = [a.split("=") for a in os.environ.get("MGX_BENCH_PARAMS", "").split(",") if a]
+    for k, v in params:
+        ctx.set_param(k, int(v))
 
     if not slabbed:
         mg = P.MultiGrid3D(ctx, [n] * 3, R3, dtype)
@@ -354,6 +359,7 @@ def main():
                                "z-slab decomposition over %d GPU%s: %d distributed levels (ghost planes over RCCL), %d replicated"
                                % (world, "s" if world > 1 else "", nd, nlev - nd),
                 "note": "N=1 runs BASELINE configs[3] (513^3); N>1 runs configs[4] (1025^3) as one strong-scaled problem",
+                "params": {k: int(v) for k, v in params} or None,
             },
             "roofline": {
                 "bound": "hbm",

@@ -86,6 +86,10 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         /* previous cycle's residual+restrict); cleared by InitF / upload_f / Restrict / setToValue.    */ \
         /* Those entries are never read by any operator; the flag only saves re-zeroing them.           */ \
         unsigned char f_rim_zero[MG_MAX_LEVELS];                                                         \
+        /* internal: 1 when the boundary (and pad) entries of level l's d_v are known to be 0: the coarse */ \
+        /* error then starts a cycle without a zero fill (relax_from_zero).  Cleared by upload_v and by  */ \
+        /* setToValue(d_v, value != 0, true).                                                            */ \
+        unsigned char v_rim_zero[MG_MAX_LEVELS];                                                         \
     } mgMultiGrid3D_##R;                                                                                 \
     int mgMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6],     \
                                    mgMultiGrid3D_##R** out);                                             \

@@ -149,6 +149,11 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
 #define MGX_DECLARE_OPS(SFX, real)                                                                      \
     int mgx3d_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3],        \
                           int ncycles);                                                                 \
+    /* relax_from_zero: v := 0 everywhere (setToValue(v, 0, true), N3/MultiGrid3D.cpp:634), then ncycles */ \
+    /* sweeps (:626).  rim_is_zero != 0: the boundary (and pad) entries of v are zero already -- then      */ \
+    /* nothing is filled and the first red pass does not read v; same bits either way.                   */ \
+    int mgx3d_relax_from_zero_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], \
+                                    int ncycles, int rim_is_zero);                                      \
     int mgx3d_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3],       \
                              const real h[3], int mode);                                                \
     int mgx3d_restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse,             \
@@ -190,6 +195,8 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx3dxs_unpack_##SFX(mgx_ctx* ctx, const real* xsplit, real* natural, const int n[3]);          \
     int mgx3dxs_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3],      \
                             int ncycles);                                                               \
+    int mgx3dxs_relax_from_zero_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3],             \
+                                      const real h[3], int ncycles, int rim_is_zero);                   \
     int mgx3dxs_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3],     \
                                const real h[3], int mode);                                              \
     int mgx3dxs_restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse,           \

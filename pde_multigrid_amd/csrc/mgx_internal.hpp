@@ -26,6 +26,8 @@ struct mgx_ctx {
     int relax_lds = -1;  // smoother kernel choice: -1 automatic, 0 relax3d_xs_kernel, shape codes see relax3d_xs_pass_lds
     int rr_cr = 0, rr_tyw = 4;  // streaming residual+restrict: coarse rows per lane, waves per block
     int rr_pzchunk = 0;    // coarse planes per block of residual_restrict3d_kernel, 0 = automatic
+    int relax_zero_first = 1;  // relax_from_zero: the first red pass on a zeroed level does not read v (and nothing is filled)
+    int relax_v2 = 1;      // fp32 smoother on wide levels: two x-pairs per lane (8-byte loads)
     int corr_fuse = 1;     // interpolate_correct_relax3d: the first red pass applies the coarse-grid correction on the fly
     int cyc2_tile = 0;     // tile edge of the cache-resident 2D cycle kernels: 0 = by level size, 16 / 32 / 64
     int cyc2_tail_points = 33 * 33;  // largest top level (points) handed to the one-workgroup tail kernel of the 2D cycle (measured:

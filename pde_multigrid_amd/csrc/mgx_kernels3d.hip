@@ -62,6 +62,29 @@ __global__ void __launch_bounds__(256) relax3d_colour_kernel(real* __restrict__ 
     v[i] = relax3d_point<real>(O, E, N, S, D, U, f[i], hx2, hy2, hz2);
 }
 
+// ------------------------------------------------------------------ relax, first red pass on v = 0
+// The coarse error starts every cycle as zero (setToValue(coarse v, 0, true), N3/MultiGrid3D.cpp:634).  The first colour
+// pass of the pre-smoothing then reads only zeros: its result is relax3d_point(0, 0, 0, 0, 0, 0, f) -- evaluated as such,
+// so the IEEE result (signs of zeros included) is what the generic pass computes from a zeroed array -- and neither the
+// zero fill of v nor the read of v is needed: f of the colour is streamed in, v of the colour streamed out.  The other
+// colour's interior points are stale afterwards; the pass that follows reads only this colour and rewrites them all.
+// Requires the boundary entries of v to be zero in memory (the host layer tracks that).
+template <class real, class L>
+__global__ void __launch_bounds__(256) relax3d_zero_colour_kernel(real* __restrict__ v, const real* __restrict__ f, int sx, int sy,
+                                                                  real hx2, real hy2, real hz2, int colour) {
+    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = 1 + blockIdx.z;
+    if (y >= sy - 1) return;
+    const int p = (colour + y + z) & 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // x = 2i + p
+    const int x = 2 * i + p;
+    if (x < 1 || x >= sx - 1) return;
+    const Geo<L, real> g(sx, sy);
+    const size_t idx = g.row(y, z) + g.pos(x);
+    const real zero = (real)0;
+    __builtin_nontemporal_store(relax3d_point<real>(zero, zero, zero, zero, zero, zero, f[idx], hx2, hy2, hz2), &v[idx]);
+}
+
 // ------------------------------------------------------------------ relax, one colour, XSplit
 // Lane j of a wave owns the x-pair {2j, 2j+1} of R consecutive rows and marches through the planes
 // [z0, z1) of its z-chunk.  In plane z the point of `colour` in the pair of row y is x = 2j + q,
@@ -660,6 +683,180 @@ __global__ void __launch_bounds__(64 * WX * WY)
 #undef MGX_K_REQUEST
 #undef MGX_K_STORE
 #undef MGX_CORR_PAIR
+}
+
+// ------------------------------------------------------------------ relax, one colour, XSplit, pipelined, TWO pairs per lane
+// relax3d_xs_pipe_kernel for fp32: with one x-pair per lane a wave instruction moves only 256 bytes and every shape of
+// that kernel stops at 0.64-0.66 of the HBM peak (profiles/r01_sweep_pipe_513_f32.txt: flat over shapes and run lengths).
+// Here a lane owns the two consecutive pairs j0 = 2 l, j0 + 1 of each of its R rows: every load and store of the column is
+// an 8-byte vector (512 bytes per wave instruction, as in fp64).  Same schedule (LDS hand-over of edge rows / edge lanes,
+// loads one plane ahead, stores one plane behind, one barrier per plane), same per-point expression.  Of the two x
+// neighbours of an updated point one is the lane's own other-colour entry, the other one is -- depending on the element --
+// the lane's other element or the neighbouring lane's (wave shuffle; wave edge: LDS; tile edge: memory).
+template <class real>
+struct Vec2T {
+    typedef real type __attribute__((ext_vector_type(2)));
+};
+
+template <class real, int WX, int WY, int R, bool FNT = false>
+__global__ void __launch_bounds__(64 * WX * WY)
+    relax3d_xs_pipe_v2_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
+                              int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
+                              int xcd_mode) {
+    typedef typename Vec2T<real>::type vec2;
+    __shared__ vec2 ey[2][WY][WX][2][64];
+    __shared__ real ex[2][WY][WX][2][R];  // [lane 0's element 0 / lane 63's element 1]
+    const Geo<XSplit, real> g(sx, sy);
+    const int H = g.H;
+    const int M = (sx + 1) >> 1;  // M - 1 pairs hold an interior point; M - 1 is even (sx = 2^k + 1 >= 5)
+    unsigned b = blockIdx.x;
+    if (xcd_mode == 1) {
+        const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
+        b = k * per + (k < rem ? k : rem) + (b >> 3);
+    }
+    const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
+    const int lane = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int wx = w % WX, wy = w / WX;
+    const int jn = 2 * ((bx * WX + wx) * 64 + lane);  // nominal first pair of the lane
+    const bool lane_on = jn < M - 1;                  // both pairs or none (M - 1 is even)
+    const int j0 = lane_on ? jn : M - 3;
+    const int y0 = 1 + (by * WY + wy) * R;
+    const int nrows = max(0, min(R, sy - 1 - y0));
+    const int z0 = zbeg + bz * zchunk;
+    const int z1 = min(z0 + zchunk, zend);
+    if (z0 >= z1) return;
+    const int sxy = (int)g.PL;
+    const bool rimR = j0 + 1 == M - 2 || (lane == 63 && wx == WX - 1);  // E side of element 1 (q_r = 1 rows) comes from memory
+    const bool rimL = lane == 0 && wx == 0;                             // W side of element 0 (q_r = 0 rows) comes from memory
+    const int wyN = wy > 0 ? wy - 1 : 0, wyS = wy < WY - 1 ? wy + 1 : WY - 1;
+    const int wxL = wx > 0 ? wx - 1 : 0, wxR = wx < WX - 1 ? wx + 1 : WX - 1;
+    int roff[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) roff[r] = min(y0 + r, sy - 1) * g.P;
+    const int roffN = (y0 - 1) * g.P, roffS = min(y0 + R, sy - 1) * g.P;
+    const real* pv = vin + (size_t)z0 * g.PL;
+    const real* pf = f + (size_t)z0 * g.PL;
+    real* po = vout + (size_t)z0 * g.PL;
+    int q = (colour + y0 + z0) & 1;
+    vec2 cp[R], cc[R], cu[R], cn[R], fc[R], fn[R], oc[R], op[R];
+    real xc[R], xn[R];
+    vec2 Nc = {0, 0}, Sc = {0, 0}, Nn = {0, 0}, Sn = {0, 0};
+#define MGX_LD2(p, i) (*(const vec2*)&(p)[(i)])
+#define MGX_LOAD_RIM2(dz, qq, X, Nv, Sv)                                                       \
+    do {                                                                                       \
+        const real* p_ = pv + (dz) * sxy;                                                      \
+        if (wy == 0) Nv = MGX_LD2(p_, roffN + (qq) * H + j0);                                  \
+        if (wy == WY - 1) Sv = MGX_LD2(p_, roffS + ((qq) ^ ((R - 1) & 1)) * H + j0);           \
+        if (rimL || rimR) {                                                                    \
+            _Pragma("unroll") for (int r = 0; r < R; r++) {                                    \
+                const int qr_ = (qq) ^ (r & 1);                                                \
+                const int d_ = qr_ ? (rimR ? 2 : 0) : (rimL ? (j0 ? -1 : M - 1) : 0);          \
+                X[r] = p_[roff[r] + (1 - qr_) * H + j0 + d_];                                  \
+            }                                                                                  \
+        }                                                                                      \
+    } while (0)
+    auto publish = [&](int slot, const vec2 (&c)[R]) __attribute__((always_inline)) {
+        ey[slot][wy][wx][0][lane] = c[0];
+        ey[slot][wy][wx][1][lane] = c[R - 1];
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) ex[slot][wy][wx][0][r] = c[r].x;
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int r = 0; r < R; r++) ex[slot][wy][wx][1][r] = c[r].y;
+        }
+    };
+    auto store_plane = [&](int dz, int qq, const vec2 (&O)[R]) __attribute__((always_inline)) {
+        real* p = po + dz * sxy;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = qq ^ (r & 1);
+            if (lane_on && r < nrows) {
+                real* d = &p[roff[r] + qr * H + j0];
+                if (qr | j0) __builtin_nontemporal_store(O[r], (vec2*)d);  // both elements are interior points
+                else __builtin_nontemporal_store(O[r].y, d + 1);          // x = 0 is a boundary point: element 1 only
+            }
+        }
+    };
+
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int qr = q ^ (r & 1);
+        cp[r] = MGX_LD2(pv, roff[r] - sxy + qr * H + j0);
+        cc[r] = MGX_LD2(pv, roff[r] + (1 - qr) * H + j0);
+        cu[r] = MGX_LD2(pv, roff[r] + sxy + qr * H + j0);
+        fc[r] = FNT ? __builtin_nontemporal_load((const vec2*)&pf[roff[r] + qr * H + j0]) : MGX_LD2(pf, roff[r] + qr * H + j0);
+        xc[r] = xn[r] = 0;
+        op[r] = vec2{0, 0};
+        cn[r] = fn[r] = oc[r] = vec2{0, 0};
+    }
+    MGX_LOAD_RIM2(0, q, xc, Nc, Sc);
+    publish(z0 & 1, cc);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int z = z0; z < z1; z++) {
+        const bool more = z + 1 < z1;
+        if (z > z0) store_plane(-1, q ^ 1, op);
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int qn = q ^ 1 ^ (r & 1);
+                cn[r] = MGX_LD2(pv, roff[r] + 2 * sxy + qn * H + j0);
+                fn[r] = FNT ? __builtin_nontemporal_load((const vec2*)&pf[roff[r] + sxy + qn * H + j0]) : MGX_LD2(pf, roff[r] + sxy + qn * H + j0);
+            }
+            MGX_LOAD_RIM2(1, q ^ 1, xn, Nn, Sn);
+            publish((z + 1) & 1, cu);
+        }
+        const int slot = z & 1;
+        const vec2 Nl = ey[slot][wyN][wx][1][lane], Sl = ey[slot][wyS][wx][0][lane];
+        const vec2 Nedge = wy > 0 ? Nl : Nc;
+        const vec2 Sedge = wy < WY - 1 ? Sl : Sc;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = q ^ (r & 1);
+            const real fromR = ex[slot][wy][wxR][0][r], fromL = ex[slot][wy][wxL][1][r];
+            // the x neighbour that is not the point's own pair: q_r = 1 -> E: element 0 takes the lane's element 1, element 1
+            // the next lane's element 0; q_r = 0 -> W: element 1 takes the lane's element 0, element 0 the previous lane's 1
+            real far;
+            if (qr) {
+                far = __shfl_down(cc[r].x, 1, 64);
+                if (lane == 63) far = fromR;
+                if (rimR) far = xc[r];
+            } else {
+                far = __shfl_up(cc[r].y, 1, 64);
+                if (lane == 0) far = fromL;
+                if (rimL) far = xc[r];
+            }
+            const vec2 N = r == 0 ? Nedge : cc[r > 0 ? r - 1 : 0];
+            const vec2 S = r == R - 1 ? Sedge : cc[r < R - 1 ? r + 1 : r];
+            const real W0 = qr ? cc[r].x : far, E0 = qr ? cc[r].y : cc[r].x;
+            const real W1 = qr ? cc[r].y : cc[r].x, E1 = qr ? far : cc[r].y;
+            oc[r].x = relax3d_point<real>(W0, E0, N.x, S.x, cp[r].x, cu[r].x, fc[r].x, hx2, hy2, hz2);
+            oc[r].y = relax3d_point<real>(W1, E1, N.y, S.y, cp[r].y, cu[r].y, fc[r].y, hx2, hy2, hz2);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            cp[r] = cc[r];
+            cc[r] = cu[r];
+            cu[r] = cn[r];
+            fc[r] = fn[r];
+            xc[r] = xn[r];
+            op[r] = oc[r];
+        }
+        Nc = Nn;
+        Sc = Sn;
+        pv += sxy;
+        pf += sxy;
+        po += sxy;
+        q ^= 1;
+    }
+    store_plane(-1, q ^ 1, op);
+#undef MGX_LOAD_RIM2
+#undef MGX_LD2
 }
 
 // ------------------------------------------------------------------ relax, whole small level in one workgroup
@@ -1705,6 +1902,26 @@ static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, in
     const int M = (sx + 1) / 2;
     int zchunk = ctx->relax_zchunk;
     int code = ctx->relax_lds;
+    if (code < 0 && sizeof(real) == 4 && ctx->relax_v2 && M - 1 >= 256 && sy - 2 >= 64 && zend - zbeg >= 8) {
+        // fp32 on wide levels: two pairs per lane (8-byte loads), 2 x 8 waves of 2 rows over 256 pairs x 16 rows
+        if (zchunk <= 0) {
+            const int tiles = ceil_div(M - 1, 256) * ceil_div(sy - 2, 16);
+            const int nchunks = max(1, (ctx->num_cus + tiles / 2) / tiles);  // one resident round of workgroups, as in fp64 (measured)
+            zchunk = max(8, ceil_div(zend - zbeg, nchunks));
+        }
+        const int gx2 = ceil_div(M - 1, 256), gy2 = ceil_div(sy - 2, 16), gz2 = ceil_div(zend - zbeg, zchunk);
+        const bool fnt = (size_t)sx * sy * (size_t)(zend - zbeg) * sizeof(real) > ((size_t)256 << 20);
+        const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
+        const dim3 grid2((unsigned)gx2 * gy2 * gz2);
+        note_relax_kernel<real>(ctx, "relax3d_xs_pipe_v2_kernel", 2, 8, 2, fnt);
+        if (fnt)
+            hipLaunchKernelGGL((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, true>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy,
+                               zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx2, gy2, xcd);
+        else
+            hipLaunchKernelGGL((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, false>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy,
+                               zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx2, gy2, xcd);
+        return true;
+    }
     if (code < 0) {
         // automatic (the default).  Measured on MI355X (tools/sweep_pipe.py, profiles/r01_sweep_pipe_*.txt): the
         // pipelined kernel with 2 x 8 waves of 2 rows wins from 257^3 up when the launch is ONE resident round of
@@ -1809,6 +2026,36 @@ int relax3d(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3
     if (L::xsplit) st = relax3d_xsplit<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles);
     else st = relax3d_natural<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles);
     if (st) return st;
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+// v := 0 (everywhere), then `ncycles` red-black sweeps: the start of the pre-smoothing of a coarse level
+// (N3/MultiGrid3D.cpp:634 + :626).  rim_is_zero != 0: the caller vouches that the boundary entries (and, x-split, the pad
+// entries) of v are zero already; then nothing is filled and the first red pass does not read v.
+template <class real, class L>
+int relax3d_from_zero(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles, int rim_is_zero) {
+    MGX_REQUIRE(ctx && v && f && h, MGX_ERR_INVALID, "relax_from_zero3d: NULL argument");
+    MGX_USE(ctx);
+    int st = check_n3(n, "relax_from_zero3d");
+    if (st) return st;
+    MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "relax_from_zero3d: ncycles = %d < 0", ncycles);
+    const bool small = n[0] <= SMALL_MAX && n[1] <= SMALL_MAX && n[2] <= SMALL_MAX && ctx->relax_small;
+    if (!rim_is_zero || ncycles == 0 || small || !ctx->relax_zero_first) {
+        const size_t elems = Geo<L, real>(n[0], n[1]).PL * (size_t)n[2];
+        st = fill_zero(ctx, v, elems * sizeof(real));
+        if (st) return st;
+        return relax3d<real, L>(ctx, v, f, n, h, ncycles);
+    }
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // :498-500
+    hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, L>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
+                       ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0);
+    for (int s = 1; s < 2 * ncycles; s++) {
+        if (L::xsplit) relax3d_xs_pass<real>(ctx, v, f, n[0], n[1], 1, n[2] - 1, hx2, hy2, hz2, s & 1);
+        else
+            hipLaunchKernelGGL((relax3d_colour_kernel<real>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
+                               ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2, hz2, s & 1);
+    }
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -2353,6 +2600,10 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
     int PFX##relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles) {    \
         return mgx::relax3d<real, L>(ctx, v, f, n, h, ncycles);                                                  \
     }                                                                                                            \
+    int PFX##relax_from_zero_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3],        \
+                                   int ncycles, int rim_is_zero) {                                               \
+        return mgx::relax3d_from_zero<real, L>(ctx, v, f, n, h, ncycles, rim_is_zero);                           \
+    }                                                                                                            \
     int PFX##residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3], const real h[3], \
                             int mode) {                                                                          \
         return mgx::residual3d<real, L>(ctx, v, f, r, n, h, mode);                                               \
@@ -2518,6 +2769,10 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "residual_restrict3d.pzchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "residual_restrict3d.pzchunk must be >= 0 (0 = automatic)");
         ctx->rr_pzchunk = value;
+    } else if (!strcmp(name, "relax3d.zero_first")) {
+        ctx->relax_zero_first = value ? 1 : 0;  // relax_from_zero: first red pass without reading v (1) or zero fill + generic passes (0)
+    } else if (!strcmp(name, "relax3d.v2")) {
+        ctx->relax_v2 = value ? 1 : 0;  // fp32, wide levels: two x-pairs per lane (relax3d_xs_pipe_v2_kernel) or one
     } else if (!strcmp(name, "relax3d.corr_fuse")) {
         ctx->corr_fuse = value ? 1 : 0;  // interpolate_correct_relax: first red pass reads the correction on the fly (1) or in-place correction first (0)
     } else if (!strcmp(name, "cycle2d.tile")) {

@@ -276,6 +276,14 @@ class _Ops3D(_Ops):
         cn = coarse_size(n)
         return self._run(ctx, [v, coarse], lambda a, c: fn(ctx._h, a, _ip(n), c, _ip(cn), C.c_int(colour)), 0, _shape(n), dtype)
 
+    def relax_from_zero(self, ctx, v, f, n, rng, ncycles, rim_is_zero, dtype=None):
+        """v := 0, then ncycles sweeps; with rim_is_zero the given v must have zero boundary entries (its interior is ignored)"""
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("relax_from_zero", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        return self._run(ctx, [v, f], lambda a, b: fn(ctx._h, a, b, _ip(n), h, C.c_int(ncycles), C.c_int(int(rim_is_zero))), 0, _shape(n),
+                         dtype)
+
     def interpolate_correct_relax(self, ctx, v, f, n, rng, coarse, ncycles, dtype=None):
         """x-split only: v += Interpolate(coarse) on the interior, then ncycles >= 1 red-black sweeps, in one call"""
         dtype = dtype or v.dtype
@@ -403,7 +411,8 @@ def _grid3_struct(ct):
         _fields_ = [("grids3D", C.POINTER(C.POINTER(Grid3D))), ("numGrids", C.c_int), ("maxGrids", C.c_int),
                     ("ctx", C.c_void_p), ("residual_mode", C.c_int), ("fuse", C.c_int), ("layout", C.c_int),
                     ("smoother", C.c_int), ("omega", ct), ("use_graph", C.c_int), ("capturing", C.c_int),
-                    ("graph_exec", C.c_void_p * 32), ("graph_key", C.c_longlong * 32), ("f_rim_zero", C.c_ubyte * 32)]
+                    ("graph_exec", C.c_void_p * 32), ("graph_key", C.c_longlong * 32), ("f_rim_zero", C.c_ubyte * 32),
+                    ("v_rim_zero", C.c_ubyte * 32)]
 
     return Grid3D, MultiGrid3D
 

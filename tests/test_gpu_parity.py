@@ -255,6 +255,54 @@ def test_3d_xsplit_interpolate_correct_relax_fused(ctx, dtype, n3):
         ctx.set_param("relax3d.zchunk", 0)
 
 
+@pytest.mark.parametrize("layout", ["natural", "xsplit"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n3", [(3, 3, 3), (9, 17, 9), (33, 17, 65), (129, 65, 17), (257, 129, 33), (513, 129, 17)])
+def test_3d_relax_from_zero(ctx, layout, dtype, n3):
+    """mgx3d[xs]_relax_from_zero == setToValue(v, 0, true) + Relax (N3/MultiGrid3D.cpp:634, :626).  With rim_is_zero the
+    first red pass does not read v and nothing is filled: v's interior is handed in as garbage (NaN) to prove it, only
+    its boundary is zero; without it v is garbage everywhere and is zero-filled first"""
+    ops = OPS3[layout]
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(sum(n3))
+    f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    zeros = np.zeros(O.shape(n3), dtype)
+    garbage = np.full(O.shape(n3), np.nan, dtype)
+    rim0 = garbage.copy()
+    rim0[0], rim0[-1], rim0[:, 0], rim0[:, -1], rim0[:, :, 0], rim0[:, :, -1] = 0, 0, 0, 0, 0, 0
+    try:
+        for zero_first in (1, 0):
+            ctx.set_param("relax3d.zero_first", zero_first)
+            for k in (0, 1, 2):
+                want = O.relax3d(n3, rg, zeros, f, k, dtype=dtype)
+                assert bits_equal(ops.relax_from_zero(ctx, garbage, f, n3, rg, k, False), want), (zero_first, k)
+                assert bits_equal(ops.relax_from_zero(ctx, rim0, f, n3, rg, k, True), want), (zero_first, k, "rim")
+    finally:
+        ctx.set_param("relax3d.zero_first", 1)
+
+
+@pytest.mark.parametrize("n3", [(513, 129, 17), (1025, 129, 17), (513, 257, 9), (2049, 129, 9), (513, 513, 33)])
+def test_3d_xsplit_relax_fp32_two_pairs_per_lane(ctx, n3):
+    """relax3d_xs_pipe_v2_kernel (fp32 on wide levels: a lane owns two x-pairs, 8-byte loads) == oracle == the one-pair
+    kernel, on rows that do and do not fill the 256-pair tiles, with every run length of the plane march"""
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(sum(n3))
+    v = rng.uniform(-1, 1, O.shape(n3)).astype(np.float32)
+    f = rng.uniform(-1, 1, O.shape(n3)).astype(np.float32)
+    want = O.relax3d(n3, rg, v, f, 2, dtype=np.float32)
+    try:
+        for v2 in (1, 0):
+            ctx.set_param("relax3d.v2", v2)
+            for zchunk in (0, 1, 3, 8, 64):
+                ctx.set_param("relax3d.zchunk", zchunk)
+                assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, rg, 2), want), (v2, zchunk)
+                if v2 and zchunk == 0 and n3[2] - 2 >= 8:
+                    assert "v2" in ctx.last_relax_kernel()
+    finally:
+        ctx.set_param("relax3d.v2", 1)
+        ctx.set_param("relax3d.zchunk", 0)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n3", [(257, 129, 33), (513, 129, 17), (257, 257, 12 + 5), (1025, 129, 9)])
 def test_3d_xsplit_relax_default_kernel_choice_large_rows(ctx, dtype, n3):

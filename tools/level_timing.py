@@ -13,8 +13,6 @@ import pde_multigrid_amd as P  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 513
 dtype = np.float32 if len(sys.argv) > 2 and sys.argv[2] == "f32" else np.float64
-for k, v in [a.split("=") for a in os.environ.get("MGX_PARAMS", "").split(",") if a]:
-    pass
 ctx = P.Context(0)
 for k, v in [a.split("=") for a in os.environ.get("MGX_PARAMS", "").split(",") if a]:
     ctx.set_param(k, int(v))
