@@ -809,11 +809,12 @@ static int allow_lds(K kernel, size_t bytes) {  // dynamic LDS beyond the 64 KB 
 }
 
 // tile edge for an sx x sy level.  Measured on MI355X (tools/time_2d.py, profiles/r02_2d_*.txt): 64-point tiles (one
-// 1024-thread workgroup per CU) from 1025^2 up, 16-point tiles (256 threads, several workgroups per CU) below; 32-point
-// tiles lose at every size (one wave per SIMD: nothing hides the LDS latency chain of a pass)
-static int cyc2_tile(const mgx_ctx* ctx, const int n[2]) {
+// 1024-thread workgroup per CU: 256 tiles) at 1025^2, 32-point tiles (512 threads, several workgroups per CU) above,
+// 16-point tiles (256 threads) below
+static int cyc2_tile(const mgx_ctx* ctx, const int n[2], size_t elem) {
     if (ctx->cyc2_tile == 16 || ctx->cyc2_tile == 32 || ctx->cyc2_tile == 64) return ctx->cyc2_tile;  // "cycle2d.tile"
     const int m = n[0] > n[1] ? n[0] : n[1];
+    if (elem == 8 && m > 1025) return 32;  // fp64 above 1025^2: 32-point tiles of 512 threads; fp32 keeps 64
     return m > 513 ? 64 : 16;
 }
 
@@ -831,7 +832,7 @@ int cycle2d_down(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const
     }
     MGX_REQUIRE(ncycles >= 0 && 2 * ncycles <= CYC2_MAXPASS, MGX_ERR_INVALID, "relax_residual_restrict2d: 0 <= ncycles <= %d", CYC2_MAXPASS / 2);
     const Lyap2<real> k = lyap<real>(h, a, A, alfa);
-    const int npass = 2 * ncycles, T = cyc2_tile(ctx, n), W = T + 3 + npass;
+    const int npass = 2 * ncycles, T = cyc2_tile(ctx, n, sizeof(real)), W = T + 3 + npass;
     const size_t lds = (size_t)2 * W * W * sizeof(real);
     const dim3 g(max(1, ceil_div(n[0] - 1, T)), max(1, ceil_div(n[1] - 1, T)));
     const int cx = coarse_f ? cn[0] : 0, cy = coarse_f ? cn[1] : 0;
@@ -842,7 +843,7 @@ int cycle2d_down(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const
                            npass, v_zero, coarse_f, cx, cy);                                                                  \
     } while (0)
     if (T == 64) MGX_CYC_DOWN(64, 1024, 3);        // 38 x 75 = 2850 points of a colour / 1024 threads
-    else if (T == 32) MGX_CYC_DOWN(32, 256, 4);    // 22 x 43 = 946 / 256
+    else if (T == 32) MGX_CYC_DOWN(32, 512, 2);    // 22 x 43 = 946 / 512
     else MGX_CYC_DOWN(16, 256, 2);                 // 14 x 27 = 378 / 256
 #undef MGX_CYC_DOWN
     MGX_LAUNCH_CHECK();
@@ -861,7 +862,7 @@ int cycle2d_up(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const i
     if (st) return st;
     MGX_REQUIRE(ncycles >= 0 && 2 * ncycles <= CYC2_MAXPASS, MGX_ERR_INVALID, "interpolate_correct_relax2d: 0 <= ncycles <= %d", CYC2_MAXPASS / 2);
     const Lyap2<real> k = lyap<real>(h, a, A, alfa);
-    const int npass = 2 * ncycles, T = cyc2_tile(ctx, n), W = T + 1 + npass, Wc = (W - 1) / 2 + 2;
+    const int npass = 2 * ncycles, T = cyc2_tile(ctx, n, sizeof(real)), W = T + 1 + npass, Wc = (W - 1) / 2 + 2;
     const size_t lds = ((size_t)2 * W * W + (size_t)Wc * Wc) * sizeof(real);
     const dim3 g(max(1, ceil_div(n[0] - 1, T)), max(1, ceil_div(n[1] - 1, T)));
 #define MGX_CYC_UP(TT, NT, NP)                                                                                              \
@@ -871,7 +872,7 @@ int cycle2d_up(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const i
                            npass, coarse_v, cn[0], cn[1]);                                                                  \
     } while (0)
     if (T == 64) MGX_CYC_UP(64, 1024, 3);
-    else if (T == 32) MGX_CYC_UP(32, 256, 4);
+    else if (T == 32) MGX_CYC_UP(32, 512, 2);
     else MGX_CYC_UP(16, 256, 2);
 #undef MGX_CYC_UP
     MGX_LAUNCH_CHECK();
