@@ -104,6 +104,8 @@ int mgx_memset_zero(mgx_ctx* ctx, void* dst, size_t bytes);                     
 /* HIP graphs for the launch-bound parts (2D cycles, coarse 3D levels): everything the calls between _begin and _end
  * enqueue on the context's compute stream is captured instead of executed and instantiated as one executable graph;
  * _launch replays it with a single launch.  The host layer's VCycle does this itself when `use_graph` is set. */
+/* A captured graph freezes the launch sequence as it was at capture time, context parameters (mgx_ctx_set_param) included:
+ * change a parameter -> capture again.  The host layer re-captures when the cycle's own arguments change, not on parameters. */
 int mgx_graph_begin(mgx_ctx* ctx);
 int mgx_graph_end(mgx_ctx* ctx, void** graph_exec);
 int mgx_graph_launch(mgx_ctx* ctx, void* graph_exec);
@@ -230,6 +232,10 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     /* interpolate_correct writes the fine planes 2pz and 2pz+1 of every listed pz (z = 0 skipped).   */ \
     int mgx3dxs_relax_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy,           \
                                         const real h[3], int colour, int zbeg, int zend, int zoff);     \
+    /* relax_zero_colour_slab: the same pass on a slab whose v counts as all zeros (the coarse error    */ \
+    /* at the start of a cycle): v is not read, no ghost plane is needed; boundary entries must be 0   */ \
+    int mgx3dxs_relax_zero_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy,      \
+                                             const real h[3], int colour, int zbeg, int zend, int zoff); \
     int mgx3dxs_residual_restrict_slab_##SFX(mgx_ctx* ctx, const real* v, const real* f,                \
                                              const int n[3], int fzoff, const real h[3], int mode,      \
                                              real* coarse_f, const int cn[3], int czoff, int pzbeg,     \

@@ -71,9 +71,9 @@ __global__ void __launch_bounds__(256) relax3d_colour_kernel(real* __restrict__ 
 // Requires the boundary entries of v to be zero in memory (the host layer tracks that).
 template <class real, class L>
 __global__ void __launch_bounds__(256) relax3d_zero_colour_kernel(real* __restrict__ v, const real* __restrict__ f, int sx, int sy,
-                                                                  real hx2, real hy2, real hz2, int colour) {
+                                                                  real hx2, real hy2, real hz2, int colour, int zbeg) {
     const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int z = 1 + blockIdx.z;
+    const int z = zbeg + blockIdx.z;  // local plane; `colour` already includes the parity of a slab's global z offset
     if (y >= sy - 1) return;
     const int p = (colour + y + z) & 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // x = 2i + p
@@ -2049,7 +2049,7 @@ int relax3d_from_zero(mgx_ctx* ctx, real* v, const real* f, const int n[3], cons
     }
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // :498-500
     hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, L>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
-                       ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0);
+                       ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0, 1);
     for (int s = 1; s < 2 * ncycles; s++) {
         if (L::xsplit) relax3d_xs_pass<real>(ctx, v, f, n[0], n[1], 1, n[2] - 1, hx2, hy2, hz2, s & 1);
         else
@@ -2320,6 +2320,23 @@ int relax3d_colour_slab(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, co
                 "relax_colour_slab: bad colour / plane range");
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
     relax3d_xs_pass<real>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, (colour + zoff) & 1);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+// the first colour pass on a slab whose v counts as all zeros (relax3d_zero_colour_kernel): local planes [zbeg, zend)
+template <class real>
+int relax3d_zero_colour_slab(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, const real h[3], int colour, int zbeg, int zend,
+                             int zoff) {
+    MGX_REQUIRE(ctx && v && f && h, MGX_ERR_INVALID, "relax_zero_colour_slab: NULL argument");
+    MGX_USE(ctx);
+    MGX_REQUIRE(valid_size(sx) && valid_size(sy), MGX_ERR_SIZE, "relax_zero_colour_slab: sizes %d x %d are not 2^k+1", sx, sy);
+    MGX_REQUIRE((colour == 0 || colour == 1) && zbeg >= 1 && zend >= zbeg && zoff >= 0, MGX_ERR_INVALID,
+                "relax_zero_colour_slab: bad colour / plane range");
+    if (zend == zbeg) return MGX_OK;
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, XSplit>), dim3(ceil_div((sx + 1) / 2, 64), ceil_div(sy - 2, 4), zend - zbeg), blk(), 0,
+                       ctx->compute, v, f, sx, sy, hx2, hy2, hz2, (colour + zoff) & 1, zbeg);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -2660,6 +2677,10 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
     int mgx3dxs_relax_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, const real h[3],   \
                                         int colour, int zbeg, int zend, int zoff) {                              \
         return mgx::relax3d_colour_slab<real>(ctx, v, f, sx, sy, h, colour, zbeg, zend, zoff);                   \
+    }                                                                                                            \
+    int mgx3dxs_relax_zero_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy,               \
+                                             const real h[3], int colour, int zbeg, int zend, int zoff) {        \
+        return mgx::relax3d_zero_colour_slab<real>(ctx, v, f, sx, sy, h, colour, zbeg, zend, zoff);              \
     }                                                                                                            \
     int mgx3dxs_residual_restrict_slab_##SFX(mgx_ctx* ctx, const real* v, const real* f, const int n[3],         \
                                              int fzoff, const real h[3], int mode, real* coarse_f,               \
