@@ -17,6 +17,9 @@ struct mgx_ctx {
     int relax_ty = 4;      // waves (row groups) per block of relax3d_xs_kernel (tuning)
     int relax_zchunk = 0;  // planes per z-chunk, 0 = automatic
     int relax_xcd = 1;     // XCD-aware block -> tile mapping
+    int rr_rcp = 1;        // residual: multiply by exact reciprocals when the squared spacings are powers of two
+    int rr_xcd = 1;        // the same for residual+restrict: 1 = the pipelined kernel only (measured: -2 % at 513^3, +14 % with
+                           // the streaming kernel at 257^3), 2 = both kernels, 0 = plain order
     int relax_rows = 4;    // consecutive rows per lane (register blocking in y) of relax3d_xs_kernel
     int relax_wave_planes = 0;  // time-skewed slab height of relax3d_xsplit: 0 off (measured slower: the L2-miss path, not HBM, is the limit), <0 automatic
     int relax_small = 1;   // levels <= 17^3: all sweeps of a Relax call in one workgroup (LDS resident)

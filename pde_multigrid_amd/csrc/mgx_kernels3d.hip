@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(64 * TYW)
     const Geo<XSplit, real> g(sx, sy);
     const int H = g.H;
     const int M = (sx + 1) >> 1;  // entries of the even-x half (the odd-x half has M-1)
+    const double rd = relax3d_rd<real>(hx2, hy2, hz2);  // fp32: the division by multiplication (relax3d_point_rd)
     // 1-D grid decoded to (bx, by, bz).  Workgroups are dealt round-robin over the 8 XCDs
     // (MI355X_MICROARCH.md: blocks b and b+8 share an XCD, each XCD has its own 4 MiB L2).
     //   xcd_mode 0: plain order, x fastest, then y tiles, then z-chunks
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(64 * TYW)
             const real E = qr ? side[r] : c_cur[r];
             const real N = r == 0 ? Nedge : c_cur[r - 1];
             const real S = r == R - 1 ? Sedge : c_cur[r + 1];
-            real out = relax3d_point<real>(W, E, N, S, c_prev[r], U[r], fv[r], hx2, hy2, hz2);
+            real out = relax3d_point_rd<real>(W, E, N, S, c_prev[r], U[r], fv[r], hx2, hy2, hz2, rd);
             if (ABL & 8) out = (W + E + N + S + c_prev[r] + U[r] - fv[r]) * hx2;
             if (ABL & 2) {
                 if (out == (real)123456.789) vout[rowb[r] + qr * H + j] = out;
@@ -418,6 +419,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
                            int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
                            int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0) {
     constexpr bool CORR = VAR == 2;
+    const double rd = relax3d_rd<real>(hx2, hy2, hz2);  // fp32: the division by multiplication (relax3d_point_rd)
     static_assert(!CORR || R == 2, "the correcting variant is written for 2 rows per lane");
     static_assert(!CORR || (WX * WY >= WY * R / 2 + 2 && WY > 1), "one wave per coarse row under the tile and its rim");
     constexpr int KR = WY * R / 2 + 1, KC = 64 * WX + 2;  // coarse rows / columns staged per plane (column 0: left of the tile, unused)
@@ -634,7 +636,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
             const real E = qr ? nb : cc[r];
             const real N = r == 0 ? Nedge : cc[r - 1];
             const real S = r == R - 1 ? Sedge : cc[r + 1];
-            oc[r] = relax3d_point<real>(W, E, N, S, cp[r], cu[r], fc[r], hx2, hy2, hz2);
+            oc[r] = relax3d_point_rd<real>(W, E, N, S, cp[r], cu[r], fc[r], hx2, hy2, hz2, rd);
         }
         real en[R];   // CORR: the correction of the entries that are on their way (plane z + 2, x = 2j + qn) ...
         bool dc[R];   // ... if they get one
@@ -709,6 +711,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
     const Geo<XSplit, real> g(sx, sy);
     const int H = g.H;
     const int M = (sx + 1) >> 1;  // M - 1 pairs hold an interior point; M - 1 is even (sx = 2^k + 1 >= 5)
+    const double rd = relax3d_rd<real>(hx2, hy2, hz2);
     unsigned b = blockIdx.x;
     if (xcd_mode == 1) {
         const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
@@ -833,8 +836,8 @@ __global__ void __launch_bounds__(64 * WX * WY)
             const vec2 S = r == R - 1 ? Sedge : cc[r < R - 1 ? r + 1 : r];
             const real W0 = qr ? cc[r].x : far, E0 = qr ? cc[r].y : cc[r].x;
             const real W1 = qr ? cc[r].y : cc[r].x, E1 = qr ? far : cc[r].y;
-            oc[r].x = relax3d_point<real>(W0, E0, N.x, S.x, cp[r].x, cu[r].x, fc[r].x, hx2, hy2, hz2);
-            oc[r].y = relax3d_point<real>(W1, E1, N.y, S.y, cp[r].y, cu[r].y, fc[r].y, hx2, hy2, hz2);
+            oc[r].x = relax3d_point_rd<real>(W0, E0, N.x, S.x, cp[r].x, cu[r].x, fc[r].x, hx2, hy2, hz2, rd);
+            oc[r].y = relax3d_point_rd<real>(W1, E1, N.y, S.y, cp[r].y, cu[r].y, fc[r].y, hx2, hy2, hz2, rd);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1408,6 +1411,20 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
     }
 }
 
+// block -> tile of a 1-D launch over gx x gy x gz tiles (x fastest).  xcd_mode 1: consecutive blocks go to the eight XCDs
+// in turn, so every XCD is given one contiguous run of the tile order -- workgroups whose tiles share rows or cache lines
+// then share an L2 (see relax3d_xs_kernel); xcd_mode 0: plain order.
+__device__ __forceinline__ void tile_of_block(int xcd_mode, int gx, int gy, int& bx, int& by, int& bz) {
+    unsigned b = blockIdx.x;
+    if (xcd_mode == 1) {
+        const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
+        b = k * per + (k < rem ? k : rem) + (b >> 3);
+    }
+    bx = b % gx;
+    by = (b / gx) % gy;
+    bz = b / (gx * gy);
+}
+
 // ------------------------------------------------------------------ residual + restrict, streaming (XSplit)
 // Lane i of a wave owns the fine x-pair {2i, 2i+1} (= coarse column i) of the 2*CR+3 fine rows around CR
 // consecutive coarse rows and marches through a chunk of coarse planes.  v is carried in registers along z
@@ -1423,14 +1440,16 @@ template <class real, int MODE, int CR, int TYW>
 __global__ void __launch_bounds__(64 * TYW)
     residual_restrict3d_xs_kernel(const real* __restrict__ v, const real* __restrict__ f, int sx, int sy, int szg, real hx2,
                                   real hy2, real hz2, real* __restrict__ coarse, int cx, int cy, int czg, int pzchunk,
-                                  int fzoff, int czoff, int pzbeg, int pzend) {
+                                  int fzoff, int czoff, int pzbeg, int pzend, int gx, int gy, int xcd_mode) {
     constexpr int NR = 2 * CR + 3;  // fine rows held per lane: residual rows 1 .. NR-2 plus one v-only row each side
     const Geo<XSplit, real> gf(sx, sy), gc(cx, cy);
     const int lane = threadIdx.x;
-    const int i = blockIdx.x * 63 + lane;
-    const int cyb = 1 + (blockIdx.y * TYW + __builtin_amdgcn_readfirstlane(threadIdx.y)) * CR;
+    int bx, by, bz;
+    tile_of_block(xcd_mode, gx, gy, bx, by, bz);
+    const int i = bx * 63 + lane;
+    const int cyb = 1 + (by * TYW + __builtin_amdgcn_readfirstlane(threadIdx.y)) * CR;
     if (cyb > cy - 2 || i > cx - 1) return;
-    int pz0 = pzbeg + blockIdx.z * pzchunk;
+    int pz0 = pzbeg + bz * pzchunk;
     const int pz1 = min(min(pz0 + pzchunk, pzend), czg - 1);
     if (pz0 < 1) pz0 = 1;
     if (pz0 >= pz1) return;
@@ -1563,18 +1582,20 @@ template <class real, int MODE, int TYW>
 __global__ void __launch_bounds__(64 * TYW)
     residual_restrict3d_xs_pipe_kernel(const real* __restrict__ v, const real* __restrict__ f, int sx, int sy, int szg,
                                        real hx2, real hy2, real hz2, real* __restrict__ coarse, int cx, int cy, int czg,
-                                       int pzchunk, int fzoff, int czoff, int pzbeg, int pzend) {
+                                       int pzchunk, int fzoff, int czoff, int pzbeg, int pzend, int gx, int gy, int xcd_mode) {
     constexpr int OWN = 4;
     __shared__ real hv[2][TYW][2][2][64];  // [plane & 1][wave][first / last own row][A / B][lane]: v
     __shared__ real hr[4][TYW][2][64];     // [plane & 3][wave][A / B][lane]: residual of the wave's first own row
     const Geo<XSplit, real> gf(sx, sy), gc(cx, cy);
     const int lane = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const int in = blockIdx.x * 62 + lane;  // nominal coarse column; lanes past the row are clamped and masked
+    int bx, by, bz;
+    tile_of_block(xcd_mode, gx, gy, bx, by, bz);
+    const int in = bx * 62 + lane;  // nominal coarse column; lanes past the row are clamped and masked
     const int i = min(in, cx - 1);
-    const int cyb = 1 + (blockIdx.y * (TYW - 1) + w) * 2;  // this wave's coarse rows: cyb, cyb + 1
-    const bool halo_wave = w == TYW - 1;                   // supplies rows to the wave above, produces nothing
-    int pz0 = pzbeg + blockIdx.z * pzchunk;
+    const int cyb = 1 + (by * (TYW - 1) + w) * 2;  // this wave's coarse rows: cyb, cyb + 1
+    const bool halo_wave = w == TYW - 1;           // supplies rows to the wave above, produces nothing
+    int pz0 = pzbeg + bz * pzchunk;
     const int pz1 = min(min(pz0 + pzchunk, pzend), czg - 1);
     if (pz0 < 1) pz0 = 1;
     if (pz0 >= pz1) return;  // uniform over the workgroup
@@ -2189,6 +2210,13 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
     if (!rim_is_zero)
         MGX_TRY_RET(fill_zero(ctx, coarse_f + gc.PL * (size_t)(pzbeg - czoff), gc.PL * (size_t)(pzend - pzbeg) * sizeof(real)));
     if (cn[0] < 3 || cn[1] < 3) return MGX_OK;
+    // power-of-two spacings: multiply by the exact reciprocals instead of dividing (residual3d_point, MODE | 2)
+    const bool rcp = ctx->rr_rcp && exact_reciprocal(hx2) && exact_reciprocal(hy2) && exact_reciprocal(hz2);
+    if (rcp) {
+        hx2 = (real)1 / hx2;
+        hy2 = (real)1 / hy2;
+        hz2 = (real)1 / hz2;
+    }
     // rr_stream 3 (default): the pipelined kernel with 8-wave workgroups on levels of at least 513 x 129 rows and 8
     // coarse planes -- measured -4 ... -8 % there (513^3, 1025^3; PMC 3.10 instead of 3.76 GB), not at 257^3
     const bool big = n[0] >= 513 && n[1] >= 129 && pzend - pzbeg >= 8;
@@ -2203,15 +2231,21 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
             const int nchunks = max(1, (target + tiles / 2) / tiles);
             pzc = max(4, ceil_div(pzend - pzbeg, nchunks));
         }
-        dim3 g(gx, gy, ceil_div(pzend - pzbeg, pzc));
+        dim3 g(gx * gy * ceil_div(pzend - pzbeg, pzc), 1, 1);
 #define MGX_RRP(M, W)                                                                                                    \
     hipLaunchKernelGGL((residual_restrict3d_xs_pipe_kernel<real, M, W>), g, dim3(64, W, 1), 0, ctx->compute, v, f, n[0],  \
-                       n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzc, fzoff, czoff, pzbeg, pzend)
+                       n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzc, fzoff, czoff, pzbeg, pzend, gx, gy, \
+                       ctx->rr_xcd >= 1)
+#define MGX_RRP_W(M)                                                                             \
+    do {                                                                                         \
+        if (T == 8) MGX_RRP(M, 8); else if (T == 2) MGX_RRP(M, 2); else MGX_RRP(M, 4);           \
+    } while (0)
         if (mode == MGX_RESIDUAL_REF_COMPAT) {
-            if (T == 8) MGX_RRP(0, 8); else if (T == 2) MGX_RRP(0, 2); else MGX_RRP(0, 4);
+            if (rcp) MGX_RRP_W(2); else MGX_RRP_W(0);
         } else {
-            if (T == 8) MGX_RRP(1, 8); else if (T == 2) MGX_RRP(1, 2); else MGX_RRP(1, 4);
+            if (rcp) MGX_RRP_W(3); else MGX_RRP_W(1);
         }
+#undef MGX_RRP_W
 #undef MGX_RRP
         return MGX_OK;
     }
@@ -2221,10 +2255,11 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
     const int gx = ceil_div(cn[0], 63), gy = ceil_div(cn[1] - 2, CRr * TYWr);
     int pzchunk = ctx->rr_pzchunk > 0 ? ctx->rr_pzchunk : 8;
     while (pzchunk > 1 && (long long)gx * gy * ceil_div(pzend - pzbeg, pzchunk) < 4LL * ctx->num_cus) pzchunk >>= 1;
-    dim3 g(gx, gy, ceil_div(pzend - pzbeg, pzchunk));
+    dim3 g(gx * gy * ceil_div(pzend - pzbeg, pzchunk), 1, 1);
 #define MGX_RR(M, C, W)                                                                                                  \
     hipLaunchKernelGGL((residual_restrict3d_xs_kernel<real, M, C, W>), g, dim3(64, W, 1), 0, ctx->compute, v, f, n[0], n[1], \
-                       n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend)
+                       n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend, gx, gy,      \
+                       ctx->rr_xcd >= 2)
 #define MGX_RR_W(M, C)                             \
     do {                                           \
         if (TYWr == 8) MGX_RR(M, C, 8);            \
@@ -2232,9 +2267,11 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
         else MGX_RR(M, C, 4);                      \
     } while (0)
     if (mode == MGX_RESIDUAL_REF_COMPAT) {
-        if (CRr == 1) MGX_RR_W(0, 1); else MGX_RR_W(0, 2);
+        if (rcp) { if (CRr == 1) MGX_RR_W(2, 1); else MGX_RR_W(2, 2); }
+        else { if (CRr == 1) MGX_RR_W(0, 1); else MGX_RR_W(0, 2); }
     } else {
-        if (CRr == 1) MGX_RR_W(1, 1); else MGX_RR_W(1, 2);
+        if (rcp) { if (CRr == 1) MGX_RR_W(3, 1); else MGX_RR_W(3, 2); }
+        else { if (CRr == 1) MGX_RR_W(1, 1); else MGX_RR_W(1, 2); }
     }
 #undef MGX_RR_W
 #undef MGX_RR
@@ -2765,6 +2802,12 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "relax3d.rows")) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.rows must be 1, 2, 4 or 8");
         ctx->relax_rows = value;
+    } else if (!strcmp(name, "residual_restrict3d.rcp")) {
+        MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "residual_restrict3d.rcp must be 0 or 1");
+        ctx->rr_rcp = value;
+    } else if (!strcmp(name, "residual_restrict3d.xcd")) {
+        MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "residual_restrict3d.xcd must be 0, 1 or 2");
+        ctx->rr_xcd = value;
     } else if (!strcmp(name, "relax3d.xcd")) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "relax3d.xcd must be 0, 1 or 2");
         ctx->relax_xcd = value;

@@ -5,6 +5,7 @@
 // each keeps the reference's association order so that results are bit-identical
 // (-ffp-contract=off; `/` is IEEE-correct for float and double on gfx950).
 #pragma once
+#include <cmath>
 #include <hip/hip_runtime.h>
 
 #include "mgx.h"
@@ -56,13 +57,52 @@ __device__ __forceinline__ real relax3d_point(real O, real E, real N, real S, re
            (2 * (hy2 * hz2 + hx2 * hz2 + hx2 * hy2));
 }
 
+// relax3d_point for a kernel that updates many points per thread: `rd` = relax3d_rd(hx2, hy2, hz2), formed once.
+// fp64: the plain expression.  fp32: the quotient num / den is (float)((double)num * RN53(1 / den)) -- the same bits as the
+// IEEE fp32 division, for three instructions instead of eleven: the product is within 2^-52 (relative) of num / den, while
+// the quotient of two 24-bit significands lies at least 2^-49 (relative) from every midpoint of two neighbouring fp32
+// numbers (num 2^24 - (2M + 1) den is a non-zero integer), so rounding the product to fp32 rounds the way rounding the
+// exact quotient does.  That argument needs a normal result: anything below FLT_MIN (zero included) is divided for real.
+template <class real>
+__device__ __forceinline__ double relax3d_rd(real hx2, real hy2, real hz2) {
+    if constexpr (sizeof(real) == 4) return 1.0 / (double)(2 * (hy2 * hz2 + hx2 * hz2 + hx2 * hy2));
+    return 0.0;
+}
+template <class real>
+__device__ __forceinline__ real relax3d_point_rd(real O, real E, real N, real S, real D, real U, real f, real hx2, real hy2,
+                                                 real hz2, double rd) {
+    if constexpr (sizeof(real) == 4) {
+        const real num = O * (hy2 * hz2) + E * (hy2 * hz2) + N * (hx2 * hz2) + S * (hx2 * hz2) + D * (hx2 * hy2) + U * (hx2 * hy2) -
+                         f * hx2 * hy2 * hz2;
+        real q = (real)((double)num * rd);
+        if (__builtin_expect(!(__builtin_fabsf(q) >= 1.17549435e-38f), 0)) q = num / (2 * (hy2 * hz2 + hx2 * hz2 + hx2 * hy2));
+        return q;
+    } else {
+        return relax3d_point<real>(O, E, N, S, D, U, f, hx2, hy2, hz2);
+    }
+}
+
 // MultiGrid3D::CalculateResidual interior expression.       N3/MultiGrid3D.cpp:723
 // MODE 0 = REF_COMPAT (the reference's -S / -U), MODE 1 = CORRECT (+S / +U).
+// MODE | 2: hx2, hy2, hz2 hold the RECIPROCALS of the squared spacings and the three divisions become multiplications.
+// The host asks for this only when all three squared spacings are powers of two (the unit cube on 2^k + 1 points, the
+// reference's own set-up): then 1 / h2 is exact, t / h2 and t * (1 / h2) are the correctly rounded value of the same real
+// number, i.e. the same bits (overflow and gradual underflow included), and an IEEE fp64 division -- about fifteen
+// instructions on CDNA -- costs one.
 template <class real, int MODE>
 __device__ __forceinline__ real residual3d_point(real O, real E, real N, real S, real D, real U, real c, real f,
                                                  real hx2, real hy2, real hz2) {
+    if (MODE == 2) return f - ((O - 2 * c + E) * hx2) - ((N - 2 * c - S) * hy2) - ((D - 2 * c - U) * hz2);
+    if (MODE == 3) return f - ((O - 2 * c + E) * hx2) - ((N - 2 * c + S) * hy2) - ((D - 2 * c + U) * hz2);
     if (MODE == 0) return f - ((O - 2 * c + E) / hx2) - ((N - 2 * c - S) / hy2) - ((D - 2 * c - U) / hz2);
     return f - ((O - 2 * c + E) / hx2) - ((N - 2 * c + S) / hy2) - ((D - 2 * c + U) / hz2);
+}
+
+// is 1 / h exact (h a normal power of two with a normal reciprocal)?
+template <class real>
+static inline bool exact_reciprocal(real h) {
+    int e;
+    return h > 0 && std::isnormal(h) && std::frexp(h, &e) == (real)0.5 && std::isnormal((real)1 / h);
 }
 
 // MultiGrid3D::Restrict interior formula.                   N3/MultiGrid3D.cpp:122-180

@@ -123,6 +123,28 @@ def test_3d_xsplit_residual_restrict_variants(ctx, n3, stream):
         ctx.set_param("residual_restrict3d.tyw", 4)
 
 
+@pytest.mark.parametrize("n3", [(9, 9, 9), (65, 33, 17), (129, 129, 33), (513, 129, 17), (513, 257, 33)])
+def test_3d_xsplit_residual_restrict_power_of_two_spacings(ctx, n3):
+    """squared spacings that are powers of two (the unit cube, [-1,1] x [0,2] x [0,4]): the residual multiplies by the exact
+    reciprocals instead of dividing (residual_restrict3d.rcp, default on) == dividing == oracle; a box with one spacing
+    that is not a power of two takes the dividing kernels whatever the switch says.  Block orders 0 / 1 / 2 as well."""
+    rng = np.random.default_rng(sum(n3))
+    try:
+        for rg in ([0, 1, 0, 1, 0, 1], [-1, 1, 0, 2, 0, 4], [0, 1, 0, 3, 0, 1]):
+            for dtype in (np.float32, np.float64):
+                v = (rng.uniform(-1, 1, O.shape(n3)) * 10.0 ** rng.integers(-30, 30)).astype(dtype)
+                f = (rng.uniform(-1, 1, O.shape(n3)) * 10.0 ** rng.integers(-30, 30)).astype(dtype)
+                for mode in (P.REF_COMPAT, P.CORRECT):
+                    want = O.restrict3d(n3, O.residual3d(n3, rg, v, f, mode, dtype=dtype), dtype=dtype)
+                    for rcp, xcd in ((1, 1), (0, 1), (1, 0), (1, 2)):
+                        ctx.set_param("residual_restrict3d.rcp", rcp)
+                        ctx.set_param("residual_restrict3d.xcd", xcd)
+                        assert bits_equal(P.ops3dxs.residual_restrict(ctx, v, f, n3, rg, mode), want), (rg, dtype, mode, rcp, xcd)
+    finally:
+        ctx.set_param("residual_restrict3d.rcp", 1)
+        ctx.set_param("residual_restrict3d.xcd", 1)
+
+
 @pytest.mark.parametrize("layout", ["natural", "xsplit"])
 @pytest.mark.parametrize("n3", [(3, 3, 3), (5, 9, 17), (17, 17, 17), (17, 5, 3), (9, 17, 9)])
 def test_3d_small_level_one_workgroup_relax(ctx, n3, layout):
