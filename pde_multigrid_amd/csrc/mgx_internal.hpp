@@ -17,6 +17,7 @@ struct mgx_ctx {
     int relax_ty = 4;      // waves (row groups) per block of relax3d_xs_kernel (tuning)
     int relax_zchunk = 0;  // planes per z-chunk, 0 = automatic
     int relax_xcd = 1;     // XCD-aware block -> tile mapping
+    int rr_rows = 0;       // fine rows per wave of the pipelined residual+restrict kernel (0: by level size; 2: sixteen waves)
     int rr_rcp = 1;        // residual: multiply by exact reciprocals when the squared spacings are powers of two
     int rr_xcd = 1;        // the same for residual+restrict: 1 = the pipelined kernel only (measured: -2 % at 513^3, +14 % with
                            // the streaming kernel at 257^3), 2 = both kernels, 0 = plain order

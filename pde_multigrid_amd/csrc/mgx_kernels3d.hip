@@ -1578,12 +1578,12 @@ __device__ __forceinline__ real wave_from_next_lane(real x) {  // lane i gets la
     }
 }
 
-template <class real, int MODE, int TYW>
+template <class real, int MODE, int TYW, int OWN = 4>
 __global__ void __launch_bounds__(64 * TYW)
     residual_restrict3d_xs_pipe_kernel(const real* __restrict__ v, const real* __restrict__ f, int sx, int sy, int szg,
                                        real hx2, real hy2, real hz2, real* __restrict__ coarse, int cx, int cy, int czg,
                                        int pzchunk, int fzoff, int czoff, int pzbeg, int pzend, int gx, int gy, int xcd_mode) {
-    constexpr int OWN = 4;
+    static_assert(OWN == 2 || OWN == 4, "a wave owns one or two coarse rows");
     __shared__ real hv[2][TYW][2][2][64];  // [plane & 1][wave][first / last own row][A / B][lane]: v
     __shared__ real hr[4][TYW][2][64];     // [plane & 3][wave][A / B][lane]: residual of the wave's first own row
     const Geo<XSplit, real> gf(sx, sy), gc(cx, cy);
@@ -1593,7 +1593,7 @@ __global__ void __launch_bounds__(64 * TYW)
     tile_of_block(xcd_mode, gx, gy, bx, by, bz);
     const int in = bx * 62 + lane;  // nominal coarse column; lanes past the row are clamped and masked
     const int i = min(in, cx - 1);
-    const int cyb = 1 + (by * (TYW - 1) + w) * 2;  // this wave's coarse rows: cyb, cyb + 1
+    const int cyb = 1 + (by * (TYW - 1) + w) * (OWN / 2);  // this wave's coarse rows: cyb (, cyb + 1)
     const bool halo_wave = w == TYW - 1;           // supplies rows to the wave above, produces nothing
     int pz0 = pzbeg + bz * pzchunk;
     const int pz1 = min(min(pz0 + pzchunk, pzend), czg - 1);
@@ -1674,7 +1674,7 @@ __global__ void __launch_bounds__(64 * TYW)
         }
         if (produces) {
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < OWN / 2; c++) {
                 const int py = cyb + c;
                 if (py <= cy - 2) {
                     const int rn = 2 * c, rc = 2 * c + 1, rs = 2 * c + 2;
@@ -2217,12 +2217,15 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
         hy2 = (real)1 / hy2;
         hz2 = (real)1 / hz2;
     }
-    // rr_stream 3 (default): the pipelined kernel with 8-wave workgroups on levels of at least 513 x 129 rows and 8
-    // coarse planes -- measured -4 ... -8 % there (513^3, 1025^3; PMC 3.10 instead of 3.76 GB), not at 257^3
-    const bool big = n[0] >= 513 && n[1] >= 129 && pzend - pzbeg >= 8;
+    // rr_stream 3 (default): the pipelined kernel on levels of at least 129 x 65 rows and 8 coarse planes (with two rows per
+    // wave it wins from 129^3 on: 18 against 25 us there, 75 against 97 us at 257^3; at 65^3 the streaming kernel's 6 us stand)
+    const bool big = n[0] >= 129 && n[1] >= 65 && pzend - pzbeg >= 8;
     if (ctx->rr_stream == 2 || (ctx->rr_stream == 3 && big)) {  // residual_restrict3d_xs_pipe_kernel
-        const int T = ctx->rr_stream == 3 ? 8 : (ctx->rr_tyw == 8 ? 8 : (ctx->rr_tyw == 2 ? 2 : 4));
-        const int gx = ceil_div(cn[0] - 2, 62), gy = ceil_div(cn[1] - 2, 2 * (T - 1));  // the last wave is a halo wave
+        // fine rows per wave: 2 (sixteen waves of <= 128 VGPRs per workgroup) up to 513 points per row, 4 (eight waves of 240
+        // VGPRs) above -- measured 513^3: 512-536 us against 562-569 us, 1025^3: 4.31 ms against 3.82 ms
+        const int own = ctx->rr_rows ? ctx->rr_rows : (n[0] > 513 ? 4 : 2);
+        const int T = own == 2 ? 16 : (ctx->rr_stream == 3 ? 8 : (ctx->rr_tyw == 8 ? 8 : (ctx->rr_tyw == 2 ? 2 : 4)));
+        const int gx = ceil_div(cn[0] - 2, 62), gy = ceil_div(cn[1] - 2, (own / 2) * (T - 1));  // the last wave is a halo wave
         int pzc = ctx->rr_pzchunk;
         if (pzc <= 0) {
             // about three resident rounds of workgroups (240 VGPRs: one 8-wave workgroup per CU at a time); the count is
@@ -2232,13 +2235,13 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
             pzc = max(4, ceil_div(pzend - pzbeg, nchunks));
         }
         dim3 g(gx * gy * ceil_div(pzend - pzbeg, pzc), 1, 1);
-#define MGX_RRP(M, W)                                                                                                    \
-    hipLaunchKernelGGL((residual_restrict3d_xs_pipe_kernel<real, M, W>), g, dim3(64, W, 1), 0, ctx->compute, v, f, n[0],  \
-                       n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzc, fzoff, czoff, pzbeg, pzend, gx, gy, \
-                       ctx->rr_xcd >= 1)
-#define MGX_RRP_W(M)                                                                             \
-    do {                                                                                         \
-        if (T == 8) MGX_RRP(M, 8); else if (T == 2) MGX_RRP(M, 2); else MGX_RRP(M, 4);           \
+#define MGX_RRP(M, W, OW)                                                                                                \
+    hipLaunchKernelGGL((residual_restrict3d_xs_pipe_kernel<real, M, W, OW>), g, dim3(64, W, 1), 0, ctx->compute, v, f,    \
+                       n[0], n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzc, fzoff, czoff, pzbeg, pzend,   \
+                       gx, gy, ctx->rr_xcd >= 1)
+#define MGX_RRP_W(M)                                                                                                     \
+    do {                                                                                                                 \
+        if (T == 16) MGX_RRP(M, 16, 2); else if (T == 8) MGX_RRP(M, 8, 4); else if (T == 2) MGX_RRP(M, 2, 4); else MGX_RRP(M, 4, 4); \
     } while (0)
         if (mode == MGX_RESIDUAL_REF_COMPAT) {
             if (rcp) MGX_RRP_W(2); else MGX_RRP_W(0);
@@ -2802,6 +2805,9 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "relax3d.rows")) {
         MGX_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, MGX_ERR_INVALID, "relax3d.rows must be 1, 2, 4 or 8");
         ctx->relax_rows = value;
+    } else if (!strcmp(name, "residual_restrict3d.rows")) {
+        MGX_REQUIRE(value == 0 || value == 2 || value == 4, MGX_ERR_INVALID, "residual_restrict3d.rows (fine rows per wave of the pipelined kernel) must be 0 (by level size), 2 or 4");
+        ctx->rr_rows = value;
     } else if (!strcmp(name, "residual_restrict3d.rcp")) {
         MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "residual_restrict3d.rcp must be 0 or 1");
         ctx->rr_rcp = value;

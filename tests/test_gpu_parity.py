@@ -113,14 +113,16 @@ def test_3d_xsplit_residual_restrict_variants(ctx, n3, stream):
             for mode in (P.REF_COMPAT, P.CORRECT):
                 want = O.restrict3d(n3, O.residual3d(n3, rg, v, f, mode, dtype=dtype), dtype=dtype)
                 for chunk in (0, 1, 3):
-                    for tyw in (4, 2, 8):
+                    for tyw, rows in ((4, 4), (2, 4), (8, 4), (4, 2)):
                         ctx.set_param("residual_restrict3d.pzchunk", chunk)
                         ctx.set_param("residual_restrict3d.tyw", tyw)
-                        assert bits_equal(P.ops3dxs.residual_restrict(ctx, v, f, n3, rg, mode), want), (dtype, mode, chunk, tyw)
+                        ctx.set_param("residual_restrict3d.rows", rows)
+                        assert bits_equal(P.ops3dxs.residual_restrict(ctx, v, f, n3, rg, mode), want), (dtype, mode, chunk, tyw, rows)
     finally:
         ctx.set_param("residual_restrict3d.stream", 3)
         ctx.set_param("residual_restrict3d.pzchunk", 0)
         ctx.set_param("residual_restrict3d.tyw", 4)
+        ctx.set_param("residual_restrict3d.rows", 0)
 
 
 @pytest.mark.parametrize("n3", [(9, 9, 9), (65, 33, 17), (129, 129, 33), (513, 129, 17), (513, 257, 33)])
@@ -136,13 +138,15 @@ def test_3d_xsplit_residual_restrict_power_of_two_spacings(ctx, n3):
                 f = (rng.uniform(-1, 1, O.shape(n3)) * 10.0 ** rng.integers(-30, 30)).astype(dtype)
                 for mode in (P.REF_COMPAT, P.CORRECT):
                     want = O.restrict3d(n3, O.residual3d(n3, rg, v, f, mode, dtype=dtype), dtype=dtype)
-                    for rcp, xcd in ((1, 1), (0, 1), (1, 0), (1, 2)):
+                    for rcp, xcd, rows in ((1, 1, 4), (0, 1, 2), (1, 0, 2), (1, 2, 4)):
                         ctx.set_param("residual_restrict3d.rcp", rcp)
                         ctx.set_param("residual_restrict3d.xcd", xcd)
-                        assert bits_equal(P.ops3dxs.residual_restrict(ctx, v, f, n3, rg, mode), want), (rg, dtype, mode, rcp, xcd)
+                        ctx.set_param("residual_restrict3d.rows", rows)
+                        assert bits_equal(P.ops3dxs.residual_restrict(ctx, v, f, n3, rg, mode), want), (rg, dtype, mode, rcp, xcd, rows)
     finally:
         ctx.set_param("residual_restrict3d.rcp", 1)
         ctx.set_param("residual_restrict3d.xcd", 1)
+        ctx.set_param("residual_restrict3d.rows", 0)
 
 
 @pytest.mark.parametrize("layout", ["natural", "xsplit"])
