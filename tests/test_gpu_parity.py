@@ -642,6 +642,36 @@ def test_2d_unfused_cycle_path_still_matches(ctx):
     mg.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_2d_long_relax_calls_run_four_sweeps_per_launch(ctx, dtype):
+    """Relax(g, ncycles) on a level that does not fit one workgroup: up to four sweeps per launch through the tiled kernel,
+    in an even number of out-of-place launches (the result is back in d_v, no pointer changes hands) == oracle, for sweep
+    counts around the chunking's edges; the per-colour path (fuse = 1) too; a graph-captured cycle with v1 = v2 = 7"""
+    rg = [0, 20, 0, 20]
+    for n2 in ((129, 129), (257, 129), (129, 513)):
+        rng = np.random.default_rng(sum(n2))
+        v = rng.uniform(-1, 1, O.shape(n2)).astype(dtype)
+        f = rng.uniform(-1, 1, O.shape(n2)).astype(dtype)
+        for fuse in (2, 1):
+            mg = P.MultiGrid2D(ctx, n2, rg, A2, 2, dtype, fuse=fuse)
+            ptr = mg.grid(0).d_v
+            for sweeps in (2, 3, 4, 5, 8, 9, 13, 30) if fuse == 2 else (5,):
+                mg.upload_v(0, v)
+                mg.upload_f(0, f)
+                mg.Relax(0, sweeps)
+                assert mg.grid(0).d_v == ptr
+                assert bits_equal(mg.download_v(0), O.relax2d(n2, rg, A2, 2, v, f, sweeps, dtype=dtype)), (n2, fuse, sweeps)
+            mg.close()
+    n2 = (257, 257)
+    want = O.cycle2d(n2, rg, A2, 2, mode=0, v1=7, v2=7, reps=3, dtype=dtype)
+    mg = P.MultiGrid2D(ctx, n2, rg, A2, 2, dtype)
+    mg.use_graph = True
+    for _ in range(3):
+        mg.VCycle(0, 7, 7)
+    assert bits_equal(mg.download_v(0), want)
+    mg.close()
+
+
 def test_2d_baseline_config1_1025_f64(ctx):
     """BASELINE.json configs[1]: 2D Lyapunov 1024x1024 (1025 points/axis), 7-level V-cycle, fp64."""
     mg = P.MultiGrid2D(ctx, [1025] * 2, [0, 1, 0, 1], A2, 2, np.float64, nlevels=7)
