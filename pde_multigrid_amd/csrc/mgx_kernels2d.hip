@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(1024) relax2d_small_kernel(real* __restrict__ 
         kind[p] = -1;
         hyK1[p] = hxK2[p] = den[p] = (real)0;
         if (t < n) {
-            const int y = t / sx, x = t - y * sx;
+            const int y = SmallDiv(sx)(t), x = t - y * sx;
             sv[t] = v[t];
             sf[t] = f[t];
             if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1) {
@@ -293,7 +293,7 @@ __device__ __forceinline__ void own_points2(Pt2<real> (&pts)[NP], const Lyap2<re
         pts[s].off = -1;
         pts[s].hyK1 = pts[s].hxK2 = pts[s].den = (real)0;
         if (idx < Wh * Wy) {
-            const int ty = idx / Wh, i = idx - ty * Wh;
+            const int ty = SmallDiv(Wh)(idx), i = idx - ty * Wh;
             const int tx = 2 * i + ((c + gx0 + gy0 + ty) & 1);
             const int x = gx0 + tx, y = gy0 + ty;
             if (tx + 1 < W && ty + 1 < Wy && x >= 1 && x <= sx - 2 && y >= 1 && y <= sy - 2) pts[s] = make_pt2<real>(k, x, y, ty * W + tx);
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(NT) cycle2d_down_kernel(const real* __restrict
 #pragma unroll
         for (int s = 0; s < NL; s++) {
             const int t = threadIdx.x + s * NT;
-            const int ty = t / W, tx = t - ty * W, x = gx0 + tx, y = gy0 + ty;
+            const int ty = SmallDiv(W)(t), tx = t - ty * W, x = gx0 + tx, y = gy0 + ty;
             a[s] = b[s] = (real)0;
             if (t < W * W && x >= 0 && x < sx && y >= 0 && y < sy) {
                 const size_t i = x + (size_t)y * sx;
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(NT) cycle2d_down_kernel(const real* __restrict
     const int xe = blockIdx.x == gridDim.x - 1 ? sx : X0 + T, ye = blockIdx.y == gridDim.y - 1 ? sy : Y0 + T;
     const int cw = xe - X0, ch = ye - Y0;
     for (int t = threadIdx.x; t < cw * ch; t += NT) {
-        const int ly = t / cw, lx = t - ly * cw;
+        const int ly = SmallDiv(cw)(t), lx = t - ly * cw;
         vout[(X0 + lx) + (size_t)(Y0 + ly) * sx] = sv[(ly + 1) * W + lx + 1];
     }
     if (!coarse) return;
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(NT) cycle2d_down_kernel(const real* __restrict
     const int px0 = X0 >> 1, py0 = Y0 >> 1;
     const int pw = blockIdx.x == gridDim.x - 1 ? cx - px0 : T / 2, ph = blockIdx.y == gridDim.y - 1 ? cy - py0 : T / 2;
     for (int t = threadIdx.x; t < pw * ph; t += NT) {
-        const int ly = t / pw, lx = t - ly * pw;
+        const int ly = SmallDiv(pw)(t), lx = t - ly * pw;
         const int px = px0 + lx, py = py0 + ly;
         real out = (real)0;  // boundary coarse point: injection of a boundary residual, which is 0 (:389-392 then :95-101)
         if (px > 0 && px < cx - 1 && py > 0 && py < cy - 1) {
@@ -410,13 +410,13 @@ __global__ void __launch_bounds__(NT) cycle2d_up_kernel(const real* __restrict__
 #pragma unroll
         for (int s = 0; s < NLC; s++) {
             const int t = threadIdx.x + s * NT;
-            const int ty = t / Wc, tx = t - ty * Wc, px = px0 + tx, py = py0 + ty;
+            const int ty = SmallDiv(Wc)(t), tx = t - ty * Wc, px = px0 + tx, py = py0 + ty;
             cc[s] = (t < Wc * Wc && px < cx && py < cy) ? coarse[px + (size_t)py * cx] : (real)0;
         }
 #pragma unroll
         for (int s = 0; s < NL; s++) {
             const int t = threadIdx.x + s * NT;
-            const int ty = t / W, tx = t - ty * W, x = X0 + tx, y = Y0 + ty;
+            const int ty = SmallDiv(W)(t), tx = t - ty * W, x = X0 + tx, y = Y0 + ty;
             a[s] = b[s] = (real)0;
             if (t < W * W && x < sx && y < sy) {
                 const size_t i = x + (size_t)y * sx;
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(NT) cycle2d_up_kernel(const real* __restrict__
     __syncthreads();
     // v += Interpolate(coarse) on the interior points of the tile (N2/MultiGrid2D.cpp:153-192 then :363)
     for (int t = threadIdx.x; t < W * W; t += NT) {
-        const int ty = t / W, tx = t - ty * W, x = X0 + tx, y = Y0 + ty;
+        const int ty = SmallDiv(W)(t), tx = t - ty * W, x = X0 + tx, y = Y0 + ty;
         if (x >= 1 && x <= sx - 2 && y >= 1 && y <= sy - 2) {
             const real* c = sc + ((y >> 1) - py0) * Wc + ((x >> 1) - px0);
             const bool ox = x & 1, oy = y & 1;
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(NT) cycle2d_up_kernel(const real* __restrict__
     const int xe = blockIdx.x == gridDim.x - 1 ? sx : X0 + T, ye = blockIdx.y == gridDim.y - 1 ? sy : Y0 + T;
     const int cw = xe - X0, ch = ye - Y0;
     for (int t = threadIdx.x; t < cw * ch; t += NT) {
-        const int ly = t / cw, lx = t - ly * cw;
+        const int ly = SmallDiv(cw)(t), lx = t - ly * cw;
         vout[(X0 + lx) + (size_t)(Y0 + ly) * sx] = sv[ly * W + lx];
     }
 }
@@ -487,6 +487,7 @@ constexpr int TAIL2_PT = 5;  // points per thread of the largest tail level (65^
 // the points thread t owns on an sx x sy level held in LDS (t, t + 1024, ...): colour of an interior point or -1
 template <class real>
 __device__ __forceinline__ void tail_points2(Pt2<real> (&pts)[TAIL2_PT], int (&kind)[TAIL2_PT], int sx, int sy, const Lyap2<real>& k) {
+    const SmallDiv dsx(sx);
 #pragma unroll
     for (int s = 0; s < TAIL2_PT; s++) {
         const int t = threadIdx.x + s * 1024;
@@ -494,7 +495,7 @@ __device__ __forceinline__ void tail_points2(Pt2<real> (&pts)[TAIL2_PT], int (&k
         pts[s].off = t;
         pts[s].hyK1 = pts[s].hxK2 = pts[s].den = (real)0;
         if (t < sx * sy) {
-            const int y = t / sx, x = t - y * sx;
+            const int y = dsx(t), x = t - y * sx;
             if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1) {
                 kind[s] = (x + y) & 1;
                 pts[s] = make_pt2<real>(k, x, y, t);
@@ -572,8 +573,9 @@ __global__ void __launch_bounds__(1024) cycle2d_tail_kernel(Tail2<real> L, Lyap2
         const int cx = L.sx[l + 1], cy = L.sy[l + 1];
         real* cv = base + offv[l + 1];
         real* cf = base + offf[l + 1];
+        const SmallDiv dcx(cx);
         for (int t = threadIdx.x; t < cx * cy; t += 1024) {
-            const int py = t / cx, px = t - py * cx;
+            const int py = dcx(t), px = t - py * cx;
             real out = (real)0;  // boundary: injection of a boundary residual, which is 0 (:95-101)
             if (px > 0 && px < cx - 1 && py > 0 && py < cy - 1) {
                 const real* c = sr + 2 * px + 2 * py * sx;
@@ -595,11 +597,12 @@ __global__ void __launch_bounds__(1024) cycle2d_tail_kernel(Tail2<real> L, Lyap2
         const real* c = base + offv[l + 1];
         const int sx = L.sx[l], sy = L.sy[l], cx = L.sx[l + 1];
         tail_points2<real>(pts, kind, sx, sy, k);
+        const SmallDiv dsx(sx);
 #pragma unroll
         for (int s = 0; s < TAIL2_PT; s++)
             if (kind[s] >= 0) {
                 const int t = pts[s].off;
-                const int y = t / sx, x = t - y * sx;
+                const int y = dsx(t), x = t - y * sx;
                 const int ci = (x >> 1) + (y >> 1) * cx;
                 const bool ox = x & 1, oy = y & 1;
                 real e;

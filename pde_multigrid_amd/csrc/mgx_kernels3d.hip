@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(1024) relax3d_small_kernel(real* __restrict__ 
         kind[k] = -1;
         gidx[k] = 0;
         if (t < n) {
-            const int z = t / sxy, y = (t - z * sxy) / sx, x = t - z * sxy - y * sx;
+            const int z = SmallDiv(sxy)(t), y = SmallDiv(sx)(t - z * sxy), x = t - z * sxy - y * sx;
             gidx[k] = g.row(y, z) + g.pos(x);
             sv[t] = v[gidx[k]];
             sf[t] = f[gidx[k]];
@@ -959,8 +959,9 @@ __global__ void __launch_bounds__(1024) cycle3d_tail_kernel(Tail3<real> T, int v
     {   // top level of the tail: v as it stands (or the zeroed error of a coarse level, without reading it), f
         const Geo<L, real> g(T.sx[0], T.sy[0]);
         const int sx = T.sx[0], sxy = T.sx[0] * T.sy[0], n = sxy * T.sz[0];
+        const SmallDiv dxy(sxy), dx(sx);
         for (int t = threadIdx.x; t < n; t += 1024) {
-            const int z = t / sxy, y = (t - z * sxy) / sx, x = t - z * sxy - y * sx;
+            const int z = dxy(t), y = dx(t - z * sxy), x = t - z * sxy - y * sx;
             const size_t gi = g.row(y, z) + g.pos(x);
             base[offv[0] + t] = top_zero ? (real)0 : T.v[0][gi];
             base[offf[0] + t] = T.f[0][gi];
@@ -971,12 +972,13 @@ __global__ void __launch_bounds__(1024) cycle3d_tail_kernel(Tail3<real> T, int v
     int kind[TAIL3_PT];
     auto classify = [&](int sx, int sy, int sz) {  // colour of the interior points this thread owns, -1 otherwise
         const int sxy = sx * sy, n = sxy * sz;
+        const SmallDiv dxy(sxy), dx(sx);
 #pragma unroll
         for (int k = 0; k < TAIL3_PT; k++) {
             const int t = threadIdx.x + k * 1024;
             kind[k] = -1;
             if (t < n) {
-                const int z = t / sxy, y = (t - z * sxy) / sx, x = t - z * sxy - y * sx;
+                const int z = dxy(t), y = dx(t - z * sxy), x = t - z * sxy - y * sx;
                 if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1 && z > 0 && z < sz - 1) kind[k] = (x + y + z) & 1;
             }
         }
@@ -1010,8 +1012,9 @@ __global__ void __launch_bounds__(1024) cycle3d_tail_kernel(Tail3<real> T, int v
         const int cx = T.sx[l + 1], cy = T.sy[l + 1], cz = T.sz[l + 1], cxy = cx * cy;
         real* cv = base + offv[l + 1];
         real* cf = base + offf[l + 1];
+        const SmallDiv dcxy(cxy), dcx(cx);
         for (int t = threadIdx.x; t < cxy * cz; t += 1024) {  // Restrict (:122-180), boundary = injection of a zero residual (:113-119)
-            const int pz = t / cxy, py = (t - pz * cxy) / cx, px = t - pz * cxy - py * cx;
+            const int pz = dcxy(t), py = dcx(t - pz * cxy), px = t - pz * cxy - py * cx;
             real out = (real)0;
             if (px > 0 && px < cx - 1 && py > 0 && py < cy - 1 && pz > 0 && pz < cz - 1) {
                 const real* c = sr + 2 * px + 2 * py * sx + 2 * pz * sxy;
@@ -1030,11 +1033,12 @@ __global__ void __launch_bounds__(1024) cycle3d_tail_kernel(Tail3<real> T, int v
         const int cx = T.sx[l + 1], cxy = cx * T.sy[l + 1];
         const real hx2 = T.hx[l] * T.hx[l], hy2 = T.hy[l] * T.hy[l], hz2 = T.hz[l] * T.hz[l];
         classify(sx, sy, sz);
+        const SmallDiv dxy(sxy), dx(sx);
 #pragma unroll
         for (int k = 0; k < TAIL3_PT; k++)
             if (kind[k] >= 0) {  // Interpolate into the error, ApplyCorrection (:216-329, :672)
                 const int t = threadIdx.x + k * 1024;
-                const int z = t / sxy, y = (t - z * sxy) / sx, x = t - z * sxy - y * sx;
+                const int z = dxy(t), y = dx(t - z * sxy), x = t - z * sxy - y * sx;
                 const real* cc = c + (x >> 1) + (y >> 1) * cx + (z >> 1) * cxy;
                 const real e = interpolate3d_point<real>(x & 1, y & 1, z & 1, [&](int dx, int dy, int dz) { return cc[dx + dy * cx + dz * cxy]; });
                 sv[t] = sv[t] + e;
@@ -1046,8 +1050,9 @@ __global__ void __launch_bounds__(1024) cycle3d_tail_kernel(Tail3<real> T, int v
     for (int l = 0; l <= last; l++) {
         const Geo<L, real> g(T.sx[l], T.sy[l]);
         const int sx = T.sx[l], sxy = T.sx[l] * T.sy[l], n = sxy * T.sz[l];
+        const SmallDiv dxy(sxy), dx(sx);
         for (int t = threadIdx.x; t < n; t += 1024) {
-            const int z = t / sxy, y = (t - z * sxy) / sx, x = t - z * sxy - y * sx;
+            const int z = dxy(t), y = dx(t - z * sxy), x = t - z * sxy - y * sx;
             const size_t gi = g.row(y, z) + g.pos(x);
             T.v[l][gi] = base[offv[l] + t];
             if (l > 0) T.f[l][gi] = base[offf[l] + t];
