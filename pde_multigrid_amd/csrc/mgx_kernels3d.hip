@@ -999,11 +999,14 @@ __global__ void __launch_bounds__(1024) cycle3d_tail_kernel(Tail3<real> T, int v
             const int t = threadIdx.x + k * 1024;
             if (t < n) {
                 real r = (real)0;
-                if (kind[k] >= 0) {
-                    if (mode == MGX_RESIDUAL_REF_COMPAT)
-                        r = residual3d_point<real, 0>(sv[t - 1], sv[t + 1], sv[t - sx], sv[t + sx], sv[t - sxy], sv[t + sxy], sv[t], sf[t], hx2, hy2, hz2);
-                    else
-                        r = residual3d_point<real, 1>(sv[t - 1], sv[t + 1], sv[t - sx], sv[t + sx], sv[t - sxy], sv[t + sxy], sv[t], sf[t], hx2, hy2, hz2);
+                if (kind[k] >= 0) {  // mode | 2: the host found every level's squared spacings to be powers of two (residual3d_point)
+                    const real O = sv[t - 1], E = sv[t + 1], N = sv[t - sx], S = sv[t + sx], D = sv[t - sxy], U = sv[t + sxy], c = sv[t], ff = sf[t];
+                    switch (mode) {
+                        case 0: r = residual3d_point<real, 0>(O, E, N, S, D, U, c, ff, hx2, hy2, hz2); break;
+                        case 1: r = residual3d_point<real, 1>(O, E, N, S, D, U, c, ff, hx2, hy2, hz2); break;
+                        case 2: r = residual3d_point<real, 2>(O, E, N, S, D, U, c, ff, (real)1 / hx2, (real)1 / hy2, (real)1 / hz2); break;
+                        default: r = residual3d_point<real, 3>(O, E, N, S, D, U, c, ff, (real)1 / hx2, (real)1 / hy2, (real)1 / hz2); break;
+                    }
                 }
                 sr[t] = r;
             }
@@ -2093,13 +2096,21 @@ int residual3d(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[
     int st = check_n3(n, "residual3d");
     if (st) return st;
     MGX_REQUIRE(mode == MGX_RESIDUAL_REF_COMPAT || mode == MGX_RESIDUAL_CORRECT, MGX_ERR_INVALID, "residual3d: bad mode %d", mode);
-    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // N3/MultiGrid3D.cpp:687-689
-    if (mode == MGX_RESIDUAL_REF_COMPAT)
-        hipLaunchKernelGGL((residual3d_kernel<real, L, 0>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, v, f, r, n[0], n[1],
-                           n[2], hx2, hy2, hz2);
-    else
-        hipLaunchKernelGGL((residual3d_kernel<real, L, 1>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, v, f, r, n[0], n[1],
-                           n[2], hx2, hy2, hz2);
+    real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // N3/MultiGrid3D.cpp:687-689
+    const bool rcp = ctx->rr_rcp && exact_reciprocal(hx2) && exact_reciprocal(hy2) && exact_reciprocal(hz2);  // residual3d_point
+    if (rcp) {
+        hx2 = (real)1 / hx2;
+        hy2 = (real)1 / hy2;
+        hz2 = (real)1 / hz2;
+    }
+#define MGX_RES(M) \
+    hipLaunchKernelGGL((residual3d_kernel<real, L, M>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, v, f, r, n[0], n[1], n[2], hx2, hy2, hz2)
+    if (mode == MGX_RESIDUAL_REF_COMPAT) {
+        if (rcp) MGX_RES(2); else MGX_RES(0);
+    } else {
+        if (rcp) MGX_RES(3); else MGX_RES(1);
+    }
+#undef MGX_RES
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -2435,17 +2446,26 @@ int residual_sumsq3d_slab(mgx_ctx* ctx, const real* v, const real* f, int sx, in
         MGX_HIP(hipMemsetAsync(dev_out, 0, sizeof(double), ctx->compute));
         return MGX_OK;
     }
-    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    const bool rcp = ctx->rr_rcp && exact_reciprocal(hx2) && exact_reciprocal(hy2) && exact_reciprocal(hz2);  // residual3d_point
+    if (rcp) {
+        hx2 = (real)1 / hx2;
+        hy2 = (real)1 / hy2;
+        hz2 = (real)1 / hz2;
+    }
     const size_t rows = (size_t)(sy - 2) * (size_t)(zend - zbeg);
     void* ws = nullptr;
     MGX_TRY_RET(workspace(ctx, rows * sizeof(double), &ws));
     const dim3 g(sy - 2, zend - zbeg);
-    if (mode == MGX_RESIDUAL_REF_COMPAT)
-        hipLaunchKernelGGL((residual_sumsq3d_kernel<real, XSplit, 0>), g, dim3(256), 0, ctx->compute, v, f, sx, sy, zbeg, hx2, hy2,
-                           hz2, (double*)ws);
-    else
-        hipLaunchKernelGGL((residual_sumsq3d_kernel<real, XSplit, 1>), g, dim3(256), 0, ctx->compute, v, f, sx, sy, zbeg, hx2, hy2,
-                           hz2, (double*)ws);
+#define MGX_RES(M)                                                                                                            \
+    hipLaunchKernelGGL((residual_sumsq3d_kernel<real, XSplit, M>), g, dim3(256), 0, ctx->compute, v, f, sx, sy, zbeg, hx2, hy2, \
+                       hz2, (double*)ws)
+    if (mode == MGX_RESIDUAL_REF_COMPAT) {
+        if (rcp) MGX_RES(2); else MGX_RES(0);
+    } else {
+        if (rcp) MGX_RES(3); else MGX_RES(1);
+    }
+#undef MGX_RES
     hipLaunchKernelGGL(residual_sumsq_final_kernel, dim3(1), dim3(1024), 0, ctx->compute, (const double*)ws, rows, dev_out);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2631,7 +2651,10 @@ int cycle3d_tail(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const i
     const size_t lds = elems * sizeof(real);
     if (lds > 64 * 1024)
         MGX_HIP(hipFuncSetAttribute((const void*)cycle3d_tail_kernel<real, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((cycle3d_tail_kernel<real, L>), dim3(1), dim3(1024), lds, ctx->compute, T, v1, v2, mode, top_zero);
+    bool rcp = ctx->rr_rcp != 0;
+    for (int l = 0; l < nlev && rcp; l++)
+        rcp = exact_reciprocal(T.hx[l] * T.hx[l]) && exact_reciprocal(T.hy[l] * T.hy[l]) && exact_reciprocal(T.hz[l] * T.hz[l]);
+    hipLaunchKernelGGL((cycle3d_tail_kernel<real, L>), dim3(1), dim3(1024), lds, ctx->compute, T, v1, v2, mode | (rcp ? 2 : 0), top_zero);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
