@@ -1961,9 +1961,14 @@ static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, in
         // f is read exactly once per pass: load it non-temporally when the pass is too large to stay in the 256 MiB
         // Infinity Cache anyway (+1.5 % at 513^3 and 1025^3); a cache-resident level (257^3) is 5 % faster without
         code = (size_t)sx * sy * (size_t)(zend - zbeg) * sizeof(real) > ((size_t)256 << 20) ? 3282 : 1282;
+        // up to 257 rows (fp64): 2 x 4 waves over 8 rows, two 8-wave workgroups per CU -- twice the tiles, so runs of 16
+        // instead of 8 planes (the three planes a run loads before its first result weigh half as much): 37.3 against
+        // 39.4 us per pass at 257^3
+        const bool low = sizeof(real) == 8 && sy - 2 <= 256 && code == 1282;
+        if (low) code = 1242;
         if (zchunk <= 0) {
-            const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, 16);
-            const int target = ctx->num_cus * (sizeof(real) == 4 ? 8 : 1);
+            const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, low ? 8 : 16);
+            const int target = ctx->num_cus * (sizeof(real) == 4 ? 8 : (low ? 2 : 1));
             const int nchunks = max(1, (target + tiles / 2) / tiles);
             zchunk = max(8, ceil_div(zend - zbeg, nchunks));
         }
