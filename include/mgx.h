@@ -84,7 +84,13 @@ int mgx_ctx_device(const mgx_ctx* ctx, int* device);
  * planes per block (0 = automatic); "relax3d.xcd" 0/1/2 block-to-tile mapping (2 = every XCD owns a y-slab and walks z);
  * "relax3d.wave_planes" slab height of the time-skewed pass order (< 0 automatic, 0 = whole-grid passes);
  * "cycle2d.tile" tile edge of the cache-resident 2D kernels (0 = by level size, 16, 32, 64), "cycle2d.tail_points" largest
- * top level (in points, <= 5120) the one-workgroup tail kernel of the 2D cycle takes */
+ * top level (in points, <= 5120) the one-workgroup tail kernel of the 2D cycle takes;
+ * "relax3d.lds" kernel / shape code of the pipelined smoother (-1 automatic), "relax3d.corr_fuse", "relax3d.v2",
+ * "relax3d.zero_first", "relax3d.small" 0/1 switches of the fused forms; "residual_restrict3d.stream" 0..3 kernel choice,
+ * ".pzchunk" coarse planes per run (0 automatic), ".tyw" waves per workgroup, ".cr" coarse rows per lane, ".rows" fine rows
+ * per wave of the pipelined kernel (0 = by level size, 2, 4), ".xcd" 0/1/2 XCD-aware block order, ".rcp" 0/1: with
+ * power-of-two squared spacings the residual multiplies by the exact reciprocals instead of dividing (same bits).
+ * Unknown names and out-of-range values are rejected (MGX_ERR_INVALID). */
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value);
 /* name (kernel<template arguments>) of the smoother kernel the most recent 3D x-split colour pass launched; "" if none.
  * bench.py reports it as roofline.kernel so that the PMC traffic figure is attached only to the kernel it was taken from */

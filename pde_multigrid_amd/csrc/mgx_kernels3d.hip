@@ -2245,7 +2245,10 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
         // fine rows per wave: 2 (sixteen waves of <= 128 VGPRs per workgroup) up to 513 points per row, 4 (eight waves of 240
         // VGPRs) above -- measured 513^3: 512-536 us against 562-569 us, 1025^3: 4.31 ms against 3.82 ms
         const int own = ctx->rr_rows ? ctx->rr_rows : (n[0] > 513 ? 4 : 2);
-        const int T = own == 2 ? 16 : (ctx->rr_stream == 3 ? 8 : (ctx->rr_tyw == 8 ? 8 : (ctx->rr_tyw == 2 ? 2 : 4)));
+        // two rows per wave: sixteen waves per workgroup, eight on levels of at most 257 rows (more tiles, so longer runs:
+        // 69 against 76 us at 257^3)
+        const int T = own == 2 ? ((ctx->rr_stream == 3 ? n[1] <= 257 : ctx->rr_tyw == 8) ? 8 : 16)
+                               : (ctx->rr_stream == 3 ? 8 : (ctx->rr_tyw == 8 ? 8 : (ctx->rr_tyw == 2 ? 2 : 4)));
         const int gx = ceil_div(cn[0] - 2, 62), gy = ceil_div(cn[1] - 2, (own / 2) * (T - 1));  // the last wave is a halo wave
         int pzc = ctx->rr_pzchunk;
         if (pzc <= 0) {
@@ -2262,7 +2265,7 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
                        gx, gy, ctx->rr_xcd >= 1)
 #define MGX_RRP_W(M)                                                                                                     \
     do {                                                                                                                 \
-        if (T == 16) MGX_RRP(M, 16, 2); else if (T == 8) MGX_RRP(M, 8, 4); else if (T == 2) MGX_RRP(M, 2, 4); else MGX_RRP(M, 4, 4); \
+        if (T == 16) MGX_RRP(M, 16, 2); else if (T == 8 && own == 2) MGX_RRP(M, 8, 2); else if (T == 8) MGX_RRP(M, 8, 4); else if (T == 2) MGX_RRP(M, 2, 4); else MGX_RRP(M, 4, 4); \
     } while (0)
         if (mode == MGX_RESIDUAL_REF_COMPAT) {
             if (rcp) MGX_RRP_W(2); else MGX_RRP_W(0);

@@ -113,7 +113,7 @@ def test_3d_xsplit_residual_restrict_variants(ctx, n3, stream):
             for mode in (P.REF_COMPAT, P.CORRECT):
                 want = O.restrict3d(n3, O.residual3d(n3, rg, v, f, mode, dtype=dtype), dtype=dtype)
                 for chunk in (0, 1, 3):
-                    for tyw, rows in ((4, 4), (2, 4), (8, 4), (4, 2)):
+                    for tyw, rows in ((4, 4), (2, 4), (8, 4), (4, 2), (8, 2)):
                         ctx.set_param("residual_restrict3d.pzchunk", chunk)
                         ctx.set_param("residual_restrict3d.tyw", tyw)
                         ctx.set_param("residual_restrict3d.rows", rows)
@@ -125,7 +125,7 @@ def test_3d_xsplit_residual_restrict_variants(ctx, n3, stream):
         ctx.set_param("residual_restrict3d.rows", 0)
 
 
-@pytest.mark.parametrize("n3", [(9, 9, 9), (65, 33, 17), (129, 129, 33), (513, 129, 17), (513, 257, 33)])
+@pytest.mark.parametrize("n3", [(9, 9, 9), (65, 33, 17), (129, 129, 33), (513, 129, 17), (513, 257, 33), (513, 513, 17)])
 def test_3d_xsplit_residual_restrict_power_of_two_spacings(ctx, n3):
     """squared spacings that are powers of two (the unit cube, [-1,1] x [0,2] x [0,4]): the residual multiplies by the exact
     reciprocals instead of dividing (residual_restrict3d.rcp, default on) == dividing == oracle; a box with one spacing
