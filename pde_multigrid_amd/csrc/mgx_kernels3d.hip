@@ -2242,9 +2242,9 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
     // wave it wins from 129^3 on: 18 against 25 us there, 75 against 97 us at 257^3; at 65^3 the streaming kernel's 6 us stand)
     const bool big = n[0] >= 129 && n[1] >= 65 && pzend - pzbeg >= 8;
     if (ctx->rr_stream == 2 || (ctx->rr_stream == 3 && big)) {  // residual_restrict3d_xs_pipe_kernel
-        // fine rows per wave: 2 (sixteen waves of <= 128 VGPRs per workgroup) up to 513 points per row, 4 (eight waves of 240
-        // VGPRs) above -- measured 513^3: 512-536 us against 562-569 us, 1025^3: 4.31 ms against 3.82 ms
-        const int own = ctx->rr_rows ? ctx->rr_rows : (n[0] > 513 ? 4 : 2);
+        // fine rows per wave: 2 (sixteen waves of <= 128 VGPRs per workgroup; 513^3: 474-486 us against 562-569 us with 4
+        // rows = eight waves of 240 VGPRs; 1025^3: 3.49 against 3.76 ms -- once the runs fill whole rounds, see below)
+        const int own = ctx->rr_rows ? ctx->rr_rows : 2;
         // two rows per wave: sixteen waves per workgroup, eight on levels of at most 257 rows (more tiles, so longer runs:
         // 69 against 76 us at 257^3)
         const int T = own == 2 ? ((ctx->rr_stream == 3 ? n[1] <= 257 : ctx->rr_tyw == 8) ? 8 : 16)
@@ -2252,10 +2252,23 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
         const int gx = ceil_div(cn[0] - 2, 62), gy = ceil_div(cn[1] - 2, (own / 2) * (T - 1));  // the last wave is a halo wave
         int pzc = ctx->rr_pzchunk;
         if (pzc <= 0) {
-            // about three resident rounds of workgroups (240 VGPRs: one 8-wave workgroup per CU at a time); the count is
-            // rounded to whole rounds because all workgroups take the same time (513^3: 95 tiles x 8 runs of 32 planes)
-            const int tiles = gx * gy, target = 3 * ctx->num_cus;
-            const int nchunks = max(1, (target + tiles / 2) / tiles);
+            // whole resident rounds of workgroups, because all workgroups take the same time: three rounds for the 8-wave
+            // kernels; ONE for the 16-wave kernel (one workgroup per CU: 513^3 = 85 tiles x 3 runs of 85 coarse planes -- the
+            // three planes a run loads before its first result then weigh 2 % instead of 5 %: 512 against 540 us)
+            const int tiles = gx * gy;
+            int nchunks;
+            if (T == 16) {  // the fewest runs that fill whole rounds to 90 % (1025^3: 315 tiles x 3 = 945 of 1024 slots)
+                nchunks = 1;
+                double best = 0;
+                for (int c = 1; c <= 12; c++) {
+                    const long long w = (long long)tiles * c, cap = ctx->num_cus;
+                    const double eff = (double)w / (double)(((w + cap - 1) / cap) * cap);
+                    if (eff > best + 1e-9) { best = eff; nchunks = c; }
+                    if (eff >= 0.9) { nchunks = c; break; }
+                }
+            } else {
+                nchunks = max(1, (3 * ctx->num_cus + tiles / 2) / tiles);
+            }
             pzc = max(4, ceil_div(pzend - pzbeg, nchunks));
         }
         dim3 g(gx * gy * ceil_div(pzend - pzbeg, pzc), 1, 1);
