@@ -598,6 +598,9 @@ __global__ void __launch_bounds__(64 * WX * WY)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int z = z0; z < z1; z++) {
         const bool more = z + 1 < z1;
+        // a wave that has passed the barrier issues its stores and next loads at raised priority: requests leave the CU
+        // before the other waves' arithmetic (measured -1.3 % per pass, same-box A/B)
+        __builtin_amdgcn_s_setprio(3);
         if (z > z0) store_plane(-1, q ^ 1, op);  // results of plane z-1
         if (more) {
 #pragma unroll
@@ -616,6 +619,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
             }
             publish((z + 1) & 1, cu);
         }
+        __builtin_amdgcn_s_setprio(0);
         const int slot = z & 1;
         const real Nl = ey[slot][wyN][wx][1][lane], Sl = ey[slot][wyS][wx][0][lane];
         const real Nedge = wy > 0 ? Nl : Nc;
