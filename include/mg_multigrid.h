@@ -150,6 +150,8 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         real* d_bplane;            /* FMG: staging for the top boundary plane of the replicated f */     \
         double* d_norm;            /* device: [0] scratch of ResidualNorm, [1 ...] squared-norm history */ \
         int norm_count;            /* entries recorded by ResidualNormRecord (<= MG_NORM_HISTORY) */     \
+        long long inline_bytes;    /* levels whose slab of v is at most this large exchange inline on the */ \
+                                   /* compute stream, one launch per pass (0: always overlapped); public  */ \
     } mgDistMultiGrid3D_##R;                                                                             \
     int mgDistMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6], \
                                        int min_planes, mgDistMultiGrid3D_##R** out);                     \

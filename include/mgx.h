@@ -367,6 +367,10 @@ int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_to_lower, size_t count
                            size_t count_from_lower, const void* send_to_upper, size_t count_to_upper,
                            void* recv_from_upper, size_t count_from_upper, int elem_bytes);
 int mgx_comm_wait(mgx_ctx* ctx);
+/* on != 0: from now on collectives are enqueued on the COMPUTE stream, in order with the kernels (no overlap, no
+ * cross-stream events; mgx_comm_wait is then a no-op); 0: back to the comm stream.  Every rank switches at the same
+ * points of its schedule.  The slab driver switches per level (mgDistMultiGrid3D_*: inline_bytes). */
+int mgx_comm_set_inline(mgx_ctx* ctx, int on);
 /* all-gather `count` reals per rank (agglomeration of a coarse level) and all-reduce (sum, in place) of `count`
  * doubles (residual norm; every rank receives the same bits).  Both enqueue on the comm stream with the same
  * ordering rules, on both transports. */

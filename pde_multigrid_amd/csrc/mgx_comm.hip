@@ -65,8 +65,12 @@ struct mgx_local_group {
 
 namespace {
 
-// comm stream waits for everything enqueued so far on the compute stream
+// the stream collectives are enqueued on: the comm stream, or -- inline mode -- the compute stream itself
+inline hipStream_t cstream(const mgx_ctx* ctx) { return ctx->comm_inline ? ctx->compute : ctx->comm; }
+
+// comm stream waits for everything enqueued so far on the compute stream (inline mode: stream order does it)
 int order_after_compute(mgx_ctx* ctx) {
+    if (ctx->comm_inline) return MGX_OK;
     MGX_HIP(hipEventRecord(ctx->ev_compute, ctx->compute));
     MGX_HIP(hipStreamWaitEvent(ctx->comm, ctx->ev_compute, 0));
     return MGX_OK;
@@ -132,7 +136,7 @@ int local_begin(mgx_ctx* ctx, const Peers& peers, const void* to_lower, const vo
     const unsigned long long k = ++me.seq;
     const int s = (int)(k % mgx_local_group::SLOTS);
     MGX_TRY_RET(order_after_compute(ctx));
-    MGX_HIP(hipEventRecord(me.ready[s], ctx->comm));
+    MGX_HIP(hipEventRecord(me.ready[s], cstream(ctx)));
     {
         std::lock_guard<std::mutex> lk(g->mu);
         me.to_lower[s] = to_lower;
@@ -142,8 +146,8 @@ int local_begin(mgx_ctx* ctx, const Peers& peers, const void* to_lower, const vo
     }
     g->cv.notify_all();
     MGX_TRY_RET(wait_posted(g, peers, k, false));
-    for (int i = 0; i < peers.n; i++) MGX_HIP(hipStreamWaitEvent(ctx->comm, g->rank[peers.p[i]].ready[s], 0));
-    if (g->delay_us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, ctx->comm, (unsigned)g->delay_us);
+    for (int i = 0; i < peers.n; i++) MGX_HIP(hipStreamWaitEvent(cstream(ctx), g->rank[peers.p[i]].ready[s], 0));
+    if (g->delay_us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, cstream(ctx), (unsigned)g->delay_us);
     *k_out = k;
     return MGX_OK;
 }
@@ -152,14 +156,14 @@ int local_end(mgx_ctx* ctx, const Peers& peers, unsigned long long k) {
     mgx_local_group* g = (mgx_local_group*)ctx->local_group;
     auto& me = g->rank[ctx->rank];
     const int s = (int)(k % mgx_local_group::SLOTS);
-    MGX_HIP(hipEventRecord(me.done[s], ctx->comm));
+    MGX_HIP(hipEventRecord(me.done[s], cstream(ctx)));
     {
         std::lock_guard<std::mutex> lk(g->mu);
         me.posted_done = k;
     }
     g->cv.notify_all();
     MGX_TRY_RET(wait_posted(g, peers, k, true));
-    for (int i = 0; i < peers.n; i++) MGX_HIP(hipStreamWaitEvent(ctx->comm, g->rank[peers.p[i]].done[s], 0));
+    for (int i = 0; i < peers.n; i++) MGX_HIP(hipStreamWaitEvent(cstream(ctx), g->rank[peers.p[i]].done[s], 0));
     return MGX_OK;
 }
 
@@ -187,12 +191,12 @@ int local_halo(mgx_ctx* ctx, const void* send_lo, void* recv_lo, size_t n_from_l
     if (ctx->rank > 0 && n_from_lo) {
         const void* src = g->rank[ctx->rank - 1].to_upper[s];
         MGX_REQUIRE(src, MGX_ERR_INVALID, "halo exchange: the lower neighbour sends nothing up, but %zu elements are expected", n_from_lo);
-        MGX_HIP(hipMemcpyAsync(recv_lo, src, n_from_lo * eb, hipMemcpyDeviceToDevice, ctx->comm));
+        MGX_HIP(hipMemcpyAsync(recv_lo, src, n_from_lo * eb, hipMemcpyDeviceToDevice, cstream(ctx)));
     }
     if (ctx->rank < ctx->nranks - 1 && n_from_up) {
         const void* src = g->rank[ctx->rank + 1].to_lower[s];
         MGX_REQUIRE(src, MGX_ERR_INVALID, "halo exchange: the upper neighbour sends nothing down, but %zu elements are expected", n_from_up);
-        MGX_HIP(hipMemcpyAsync(recv_up, src, n_from_up * eb, hipMemcpyDeviceToDevice, ctx->comm));
+        MGX_HIP(hipMemcpyAsync(recv_up, src, n_from_up * eb, hipMemcpyDeviceToDevice, cstream(ctx)));
     }
     return local_end(ctx, peers, k);
 }
@@ -206,7 +210,7 @@ int local_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count, in
     for (int r = 0; r < ctx->nranks; r++) {
         const void* src = r == ctx->rank ? send : g->rank[r].gather[s];
         char* dst = (char*)recv + (size_t)r * count * eb;
-        if (src != dst) MGX_HIP(hipMemcpyAsync(dst, src, count * eb, hipMemcpyDeviceToDevice, ctx->comm));
+        if (src != dst) MGX_HIP(hipMemcpyAsync(dst, src, count * eb, hipMemcpyDeviceToDevice, cstream(ctx)));
     }
     return local_end(ctx, peers, k);
 }
@@ -217,7 +221,7 @@ int local_allreduce(mgx_ctx* ctx, double* inout, size_t count) {
     const size_t need = (size_t)ctx->nranks * count;
     if (me.red_cap < need) {
         if (me.red) {
-            MGX_HIP(hipStreamSynchronize(ctx->comm));
+            MGX_HIP(hipStreamSynchronize(cstream(ctx)));
             MGX_HIP(hipFree(me.red));
             me.red = nullptr;
             me.red_cap = 0;
@@ -231,10 +235,10 @@ int local_allreduce(mgx_ctx* ctx, double* inout, size_t count) {
     const int s = (int)(k % mgx_local_group::SLOTS);
     for (int r = 0; r < ctx->nranks; r++) {
         const void* src = r == ctx->rank ? (const void*)inout : g->rank[r].gather[s];
-        MGX_HIP(hipMemcpyAsync(me.red + (size_t)r * count, src, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm));
+        MGX_HIP(hipMemcpyAsync(me.red + (size_t)r * count, src, count * sizeof(double), hipMemcpyDeviceToDevice, cstream(ctx)));
     }
     MGX_TRY_RET(local_end(ctx, peers, k));  // nobody still reads my input: it may be overwritten in place now
-    hipLaunchKernelGGL(sum_ranks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->comm, (const double*)me.red,
+    hipLaunchKernelGGL(sum_ranks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, cstream(ctx), (const double*)me.red,
                        inout, count, ctx->nranks);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -360,12 +364,12 @@ int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_to_lower, size_t count
     const ncclDataType_t dt = dtype_of(elem_bytes);
     MGX_NCCL(ncclGroupStart());
     if (has_lo) {
-        if (count_to_lower) MGX_NCCL(ncclSend(send_to_lower, count_to_lower, dt, ctx->rank - 1, comm, ctx->comm));
-        if (count_from_lower) MGX_NCCL(ncclRecv(recv_from_lower, count_from_lower, dt, ctx->rank - 1, comm, ctx->comm));
+        if (count_to_lower) MGX_NCCL(ncclSend(send_to_lower, count_to_lower, dt, ctx->rank - 1, comm, cstream(ctx)));
+        if (count_from_lower) MGX_NCCL(ncclRecv(recv_from_lower, count_from_lower, dt, ctx->rank - 1, comm, cstream(ctx)));
     }
     if (has_up) {
-        if (count_to_upper) MGX_NCCL(ncclSend(send_to_upper, count_to_upper, dt, ctx->rank + 1, comm, ctx->comm));
-        if (count_from_upper) MGX_NCCL(ncclRecv(recv_from_upper, count_from_upper, dt, ctx->rank + 1, comm, ctx->comm));
+        if (count_to_upper) MGX_NCCL(ncclSend(send_to_upper, count_to_upper, dt, ctx->rank + 1, comm, cstream(ctx)));
+        if (count_from_upper) MGX_NCCL(ncclRecv(recv_from_upper, count_from_upper, dt, ctx->rank + 1, comm, cstream(ctx)));
     }
     MGX_NCCL(ncclGroupEnd());
     return MGX_OK;
@@ -377,8 +381,27 @@ int mgx_comm_wait(mgx_ctx* ctx) {
     MGX_USE(ctx);
     if (ctx->nranks == 1) return MGX_OK;
     if (ctx->local_group && ((mgx_local_group*)ctx->local_group)->drop_waits) return MGX_OK;  // fault injection (tests)
+    if (ctx->comm_inline) return MGX_OK;  // the collectives are on the compute stream: ordered by the stream
     MGX_HIP(hipEventRecord(ctx->ev_comm, ctx->comm));
     MGX_HIP(hipStreamWaitEvent(ctx->compute, ctx->ev_comm, 0));
+    return MGX_OK;
+}
+
+// Inline mode: collectives are enqueued on the compute stream, in order with the kernels, instead of on the comm stream
+// behind an event -- no overlap with computation, but also none of the two cross-stream dependencies an overlapped
+// exchange costs (measured 12.5 us each on MI355X / ROCm 7.2 against 2.5 us between kernels of one stream,
+// tools/debug/hop_latency.hip): the right mode for levels whose interior pass is shorter than that.  Switching it on first
+// orders the compute stream behind whatever the comm stream still holds (one communicator: its operations stay in one
+// order on every rank); every rank must switch at the same points of its schedule.
+int mgx_comm_set_inline(mgx_ctx* ctx, int on) {
+    MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_USE(ctx);
+    on = on != 0;
+    if (ctx->nranks > 1 && on && !ctx->comm_inline) {
+        MGX_HIP(hipEventRecord(ctx->ev_comm, ctx->comm));
+        MGX_HIP(hipStreamWaitEvent(ctx->compute, ctx->ev_comm, 0));
+    }
+    ctx->comm_inline = on;
     return MGX_OK;
 }
 
@@ -394,7 +417,7 @@ int mgx_comm_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count,
     MGX_REQUIRE(ctx->rccl_comm, MGX_ERR_RCCL, "communicator not initialised");
     int st = order_after_compute(ctx);
     if (st) return st;
-    MGX_NCCL(ncclAllGather(send, recv, count, dtype_of(elem_bytes), (ncclComm_t)ctx->rccl_comm, ctx->comm));
+    MGX_NCCL(ncclAllGather(send, recv, count, dtype_of(elem_bytes), (ncclComm_t)ctx->rccl_comm, cstream(ctx)));
     return MGX_OK;
 }
 
@@ -427,7 +450,7 @@ int mgx_comm_allreduce_sum_f64(mgx_ctx* ctx, double* dev_inout, size_t count) {
     MGX_REQUIRE(ctx->rccl_comm, MGX_ERR_RCCL, "communicator not initialised");
     int st = order_after_compute(ctx);
     if (st) return st;
-    MGX_NCCL(ncclAllReduce(dev_inout, dev_inout, count, ncclFloat64, ncclSum, (ncclComm_t)ctx->rccl_comm, ctx->comm));
+    MGX_NCCL(ncclAllReduce(dev_inout, dev_inout, count, ncclFloat64, ncclSum, (ncclComm_t)ctx->rccl_comm, cstream(ctx)));
     return MGX_OK;
 }
 

@@ -14,6 +14,7 @@ struct mgx_ctx {
     hipStream_t comm = nullptr;     // RCCL halo exchange / collectives
     hipEvent_t ev_compute = nullptr;  // compute -> comm ordering
     hipEvent_t ev_comm = nullptr;     // comm -> compute ordering
+    int comm_inline = 0;              // collectives are enqueued on the compute stream itself (mgx_comm_set_inline)
     int relax_ty = 4;      // waves (row groups) per block of relax3d_xs_kernel (tuning)
     int relax_zchunk = 0;  // planes per z-chunk, 0 = automatic
     int relax_xcd = 1;     // XCD-aware block -> tile mapping

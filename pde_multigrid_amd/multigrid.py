@@ -741,7 +741,7 @@ def _dist_struct(ct):
         _fields_ = [("slabs", C.POINTER(C.POINTER(Slab3D))), ("numDist", C.c_int), ("numGrids", C.c_int), ("maxGrids", C.c_int),
                     ("tail", C.c_void_p), ("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
                     ("residual_mode", C.c_int), ("d_share", C.c_void_p), ("d_bplane", C.c_void_p), ("d_norm", C.c_void_p),
-                    ("norm_count", C.c_int)]
+                    ("norm_count", C.c_int), ("inline_bytes", C.c_longlong)]
 
     return Slab3D, DistMultiGrid3D
 
@@ -752,7 +752,8 @@ class DistMultiGrid3D(_MGBase):
     in-process test transport) unless it runs alone."""
     _prefix = "mgDistMultiGrid3D"
 
-    def __init__(self, ctx, finestGridSizeXYZ, rng, dtype=np.float64, nlevels=0, residual_mode=REF_COMPAT, min_planes=4):
+    def __init__(self, ctx, finestGridSizeXYZ, rng, dtype=np.float64, nlevels=0, residual_mode=REF_COMPAT, min_planes=4,
+                 inline_bytes=None):
         self.ctx = ctx
         self.dtype = np.dtype(dtype)
         self._sfx, self._ct = _ct(dtype)
@@ -764,6 +765,12 @@ class DistMultiGrid3D(_MGBase):
         if nlevels:
             self.numGrids = nlevels
         self._mg.contents.residual_mode = int(residual_mode)
+        if inline_bytes is not None:  # None: the library default (mg_multigrid.h); 0: every level overlapped
+            self._mg.contents.inline_bytes = int(inline_bytes)
+
+    @property
+    def inline_bytes(self):
+        return self._mg.contents.inline_bytes
 
     @property
     def numDist(self):

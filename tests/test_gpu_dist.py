@@ -23,7 +23,9 @@ DELAY_US = 300  # a colour pass of these grids takes 5-50 us: every transfer arr
 
 
 def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COMPAT, v0=None, f0=None, nlevels=0, fmg=0,
-              delay_us=DELAY_US, drop_waits=False, extra=None, join_timeout=100):
+              delay_us=DELAY_US, drop_waits=False, extra=None, join_timeout=100, inline_bytes=0):
+    """inline_bytes = 0: every level runs the OVERLAPPED schedule (comm stream, edge planes first) -- what these tests were
+    written for; None: the library default (small levels exchange inline on the compute stream); a number: that threshold"""
     ctxs = [P.Context(0) for _ in range(nranks)]
     group = P.LocalGroup(nranks)
     group.set_test_hooks(delay_us, drop_waits)
@@ -34,7 +36,8 @@ def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COM
 
     def worker(r):
         try:
-            mg = P.DistMultiGrid3D(ctxs[r], n3, rng, dtype, nlevels=nlevels, residual_mode=mode, min_planes=min_planes)
+            mg = P.DistMultiGrid3D(ctxs[r], n3, rng, dtype, nlevels=nlevels, residual_mode=mode, min_planes=min_planes,
+                                   inline_bytes=inline_bytes)
             info[r] = (mg.numDist, mg.numGrids)
             if f0 is not None:
                 mg.upload_f(0, f0)
@@ -104,6 +107,28 @@ def test_dist_vcycle_wide_rows_pipelined_smoother_on_slabs(nranks, dtype):
     assert info[0][0] >= 1
     want = O.cycle3d(n3, rg, mode=0, v1=2, v2=2, reps=1, v=v0, f=f0, dtype=dtype)
     assert bits_equal(got, want)
+
+
+@pytest.mark.timeout(200)
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("inline_bytes", [None, 600_000, 100_000])
+def test_dist_inline_and_mixed_exchange_modes(nranks, inline_bytes):
+    """levels whose slab is small exchange INLINE on the compute stream (one launch per pass, no cross-stream events):
+    the library default (every level of these grids), a threshold between level 0 and level 1 (65^3 / 2 ranks: 1.08 MB
+    and 139 KB -- the mode switches in the middle of every cycle, in both directions) and one below most levels; V-cycles
+    with random inputs in both residual modes, and FMG -- bit-identical to the single-GPU result"""
+    n3 = [65, 33, 65]
+    rng = np.random.default_rng(nranks)
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    for dtype, mode in ((np.float64, P.REF_COMPAT), (np.float32, P.CORRECT)):
+        v0 = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+        f0 = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+        got, info = run_ranks(nranks, n3, rg, dtype, 2, 1, 2, 2, mode=mode, v0=v0, f0=f0, inline_bytes=inline_bytes)
+        want = O.cycle3d(n3, rg, mode=0, v1=2, v2=1, reps=2, v=v0, f=f0, residual_mode=mode, dtype=dtype)
+        assert not np.isnan(got).any()
+        assert bits_equal(got, want), (dtype, mode)
+    got, info = run_ranks(nranks, [65] * 3, R3, np.float64, 1, 2, 0, 4, fmg=2, inline_bytes=inline_bytes)
+    assert bits_equal(got, O.cycle3d([65] * 3, R3, mode=1, v0=2, v1=1, v2=2, dtype=np.float64))
 
 
 @pytest.mark.timeout(200)

@@ -47,9 +47,11 @@ for c in range(cases):
     mg.close()
     ctx.close()
     try:
-        got, info = run_ranks(nr, n, box, dtype, v1, v2, reps, mp, mode=mode, v0=v, f0=f, fmg=fmg, delay_us=200, join_timeout=120)
+        ib = [0, None, 200_000, 2_000_000][int(rng.integers(0, 4))]  # overlapped / library default / mixed thresholds
+        got, info = run_ranks(nr, n, box, dtype, v1, v2, reps, mp, mode=mode, v0=v, f0=f, fmg=fmg, delay_us=200, join_timeout=120,
+                              inline_bytes=ib)
         ok = got.tobytes() == want.tobytes()
-        what = "levels dist/all %s" % (info[0],)
+        what = "levels dist/all %s inline_bytes=%s" % (info[0], ib)
     except AssertionError as e:
         ok, what = False, str(e)[:200]
     bad += not ok
