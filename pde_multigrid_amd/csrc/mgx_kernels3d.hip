@@ -1554,13 +1554,15 @@ __global__ void __launch_bounds__(64 * TYW)
 // ------------------------------------------------------------------ residual + restrict, pipelined, halos through LDS
 // The recipe of relax3d_xs_pipe_kernel applied to residual+restrict.  residual_restrict3d_xs_kernel keeps a 7-row
 // window per lane and re-reads three of the seven rows of v (and one of five of f) that the next row group also
-// reads; those re-reads all reach the fabric (PMC: 3.76 GB for 2.16 GB of v and f at 513^3), also when the waves are
-// kept in lock-step by a barrier -- the caches do not merge them.  Here a wave owns FOUR fine rows (two coarse rows)
-// and loads nothing else: the row above and the row below its four come from the neighbouring waves of the
-// workgroup through LDS (v of the current plane), and so does the residual row the second coarse row needs from
+// reads; those re-reads all reach the fabric (PMC: 3.76 GB for 2.16 GB of v and f at 513^3) as long as neighbouring
+// workgroups sit on different XCDs (tile_of_block: with every XCD working on one contiguous run of tiles they meet in one
+// L2).  Here a wave owns OWN fine rows (OWN / 2 coarse rows; OWN = 2: sixteen waves of 122 VGPRs, the default; OWN = 4:
+// eight waves of 240) and loads nothing else: the row above and the row below its own come from the neighbouring waves of
+// the workgroup through LDS (v of the current plane), and so does the residual row the last coarse row needs from
 // below (the next wave's first row).  The last wave of a workgroup is a halo wave: it supplies those rows to the wave
 // above it and produces no output (it loads two rows of v and one of f), so a workgroup of TYW waves produces
-// 2 (TYW-1) coarse rows.  Software pipeline as in the smoother: in the step of fine plane g a wave requests v of
+// (OWN / 2) (TYW-1) coarse rows.  MODE | 2: the residual multiplies by exact reciprocals (residual3d_point) -- with three
+// IEEE divisions per point this kernel was bound by the VALU, not by memory.  Software pipeline as in the smoother: in the step of fine plane g a wave requests v of
 // plane g+2 and f of plane g+1, publishes its edge rows of plane g+1, reads its neighbours' edge rows of plane g,
 // computes the residual of plane g, publishes the residual of its first row, and meets the others at ONE barrier;
 // what it requested is waited for only after the barrier.  The coarse plane pz is formed at the start of the step
