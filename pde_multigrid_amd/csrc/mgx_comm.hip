@@ -421,7 +421,8 @@ int mgx_comm_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count,
     return MGX_OK;
 }
 
-// Grouped ncclSend/ncclRecv of `count` doubles from this rank to itself on the comm stream: exercises RCCL
+// Grouped ncclSend/ncclRecv of `count` doubles from this rank to itself on the comm stream (inline mode: on the compute
+// stream): exercises RCCL
 // linkage, communicator and stream/event plumbing on a box with a single GPU (nranks may be 1).  dev_src and
 // dev_dst must not overlap.
 int mgx_comm_selftest(mgx_ctx* ctx, const double* dev_src, double* dev_dst, size_t count) {
@@ -432,12 +433,14 @@ int mgx_comm_selftest(mgx_ctx* ctx, const double* dev_src, double* dev_dst, size
     if (st) return st;
     ncclComm_t comm = (ncclComm_t)ctx->rccl_comm;
     MGX_NCCL(ncclGroupStart());
-    MGX_NCCL(ncclSend(dev_src, count, ncclFloat64, ctx->rank, comm, ctx->comm));
-    MGX_NCCL(ncclRecv(dev_dst, count, ncclFloat64, ctx->rank, comm, ctx->comm));
+    MGX_NCCL(ncclSend(dev_src, count, ncclFloat64, ctx->rank, comm, cstream(ctx)));
+    MGX_NCCL(ncclRecv(dev_dst, count, ncclFloat64, ctx->rank, comm, cstream(ctx)));
     MGX_NCCL(ncclGroupEnd());
-    MGX_HIP(hipEventRecord(ctx->ev_comm, ctx->comm));
-    MGX_HIP(hipStreamWaitEvent(ctx->compute, ctx->ev_comm, 0));
-    MGX_HIP(hipStreamSynchronize(ctx->comm));
+    if (!ctx->comm_inline) {
+        MGX_HIP(hipEventRecord(ctx->ev_comm, ctx->comm));
+        MGX_HIP(hipStreamWaitEvent(ctx->compute, ctx->ev_comm, 0));
+    }
+    MGX_HIP(hipStreamSynchronize(cstream(ctx)));
     return MGX_OK;
 }
 

@@ -123,6 +123,10 @@ class Context:
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         check(lib.mgx_comm_init(self._h, buf, int(rank), int(nranks)))
 
+    def comm_set_inline(self, on):
+        """collectives on the compute stream (True) or on the comm stream (False): mgx_comm_set_inline"""
+        check(lib.mgx_comm_set_inline(self._h, C.c_int(int(bool(on)))))
+
 
 # --------------------------------------------------------------------------- raw operators
 def xs_geometry(sx, itemsize):

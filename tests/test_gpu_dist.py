@@ -185,6 +185,13 @@ def test_rccl_plumbing_single_rank():
     src, dst = ctx.to_device(x), ctx.malloc(x.nbytes)
     P.check(P.lib.mgx_comm_selftest(ctx._h, src, dst, C.c_size_t(x.size)))
     assert bits_equal(ctx.to_host(dst, x.shape, x.dtype), x)
+    # the same with the collectives enqueued on the compute stream (the mode of small slab levels), and back
+    for on in (True, False):
+        ctx.comm_set_inline(on)
+        y = np.random.default_rng(1 + on).uniform(-1, 1, 1 << 16)
+        P.check(P.lib.mgx_memcpy_h2d(ctx._h, src, y.ctypes.data_as(C.c_void_p), C.c_size_t(y.nbytes)))
+        P.check(P.lib.mgx_comm_selftest(ctx._h, src, dst, C.c_size_t(y.size)))
+        assert bits_equal(ctx.to_host(dst, y.shape, y.dtype), y)
     # with a (1-rank) RCCL communicator attached the slab driver still works
     mg = P.DistMultiGrid3D(ctx, [33] * 3, R3, np.float64, min_planes=2)
     mg.VCycle(0, 2, 2)
