@@ -6,8 +6,8 @@ lists multi-GPU sub-grids as future work, p. 75); the cycle being distributed is
      and ~47 GB at this size, so its result was hashed once in the build container (oracle/gen_known_f64.py) and the
      committed hashes (whole array + per block of 64 planes, tests/golden/known_answers_f64.json) are compared here;
   2. the 8-rank slab hierarchy with the bench's own parameters (min_planes 32: levels 1025 / 513 / 257 distributed with
-     128 / 64 / 32 planes per rank, 129 ... 3 replicated), thread-ranks on the asynchronous test transport with its
-     delay hook on, bit-identical to 1. on all 1.08e9 points.
+     128 / 64 / 32 planes per rank, 129 ... 3 replicated; exchange modes by the library default), thread-ranks on the
+     asynchronous test transport with its delay hook on, bit-identical to 1. on all 1.08e9 points.
 One GPU box has one GPU, so RCCL between different GPUs is still not exercised here."""
 import json
 import os
@@ -42,7 +42,9 @@ def test_config4_1025_single_gpu_vs_oracle_and_8_slabs():
     assert not bad, "plane blocks %s differ from the oracle" % bad
     assert O.fnv(single) == ka["fnv"]
 
-    got, info = run_ranks(8, [n] * 3, R3, np.float64, 2, 2, 1, 32, delay_us=500, join_timeout=900)
+    # inline_bytes = None: the library default, as in bench.py -- the 1025- and 513-levels exchange overlapped on the comm
+    # stream, the 257-level (17 MB slabs) inline on the compute stream
+    got, info = run_ranks(8, [n] * 3, R3, np.float64, 2, 2, 1, 32, delay_us=500, join_timeout=900, inline_bytes=None)
     assert info[0] == (3, 10)  # 1025, 513, 257 distributed; 129 ... 3 replicated
     assert not np.isnan(got).any()
     assert bits_equal(got, single)
