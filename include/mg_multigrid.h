@@ -90,6 +90,11 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         /* error then starts a cycle without a zero fill (relax_from_zero).  Cleared by upload_v and by  */ \
         /* setToValue(d_v, value != 0, true).                                                            */ \
         unsigned char v_rim_zero[MG_MAX_LEVELS];                                                         \
+        /* internal: 1 when the boundary entries of level l's d_e equal those of its d_v: d_e is the      */ \
+        /* ping-pong partner of the one-launch red+black sweeps (mgx3dxs_relax_pp), which never write     */ \
+        /* boundary points.  Cleared by everything that may write either array's boundary.  External      */ \
+        /* writers of d_v / d_e through the raw device pointers must clear it (and v_rim_zero) themselves. */ \
+        unsigned char e_rim_valid[MG_MAX_LEVELS];                                                        \
     } mgMultiGrid3D_##R;                                                                                 \
     int mgMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6],     \
                                    mgMultiGrid3D_##R** out);                                             \

@@ -77,7 +77,11 @@ const char* mgx_version(void);
 int mgx_device_count(int* count);
 int mgx_ctx_create(int device, mgx_ctx** out);
 int mgx_ctx_destroy(mgx_ctx* ctx);
-int mgx_ctx_sync(mgx_ctx* ctx);                 /* waits for the compute and comm streams */
+int mgx_ctx_sync(mgx_ctx* ctx);                 /* waits for the compute and comm streams, then mgx_ctx_check */
+/* MGX_OK unless an inter-workgroup wait of a one-launch red+black sweep (mgx3dxs_relax_pp) has given up on this
+ * context -- its workgroups were not resident together; results of that launch are invalid ("relax3d.fused" = 0 avoids
+ * the kernel).  Meaningful after a synchronisation. */
+int mgx_ctx_check(mgx_ctx* ctx);
 int mgx_ctx_device(const mgx_ctx* ctx, int* device);
 /* tuning knobs of the x-split smoother kernel (speed only, never results): "relax3d.ty" waves
  * per block and "relax3d.rows" consecutive rows per lane, each in {1,2,4,8}; "relax3d.zchunk"
@@ -205,6 +209,16 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                             int ncycles);                                                               \
     int mgx3dxs_relax_from_zero_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3],             \
                                       const real h[3], int ncycles, int rim_is_zero);                   \
+    /* relax_pp: the same `ncycles` sweeps of v with a second array w (mgx3dxs_elems reals) as ping-pong */ \
+    /* partner: on levels of 513-point rows every red+black sweep is ONE launch, out of place, that      */ \
+    /* moves 2.5 instead of 3 reals per point (the black stage takes the new red values of its own tile  */ \
+    /* from LDS and of the neighbouring tiles from memory, ordered by progress words; "relax3d.fused" = 0 */ \
+    /* turns it off).  Result in v, bit-identical to mgx3dxs_relax; w is scratch.  w_rim_valid != 0: the  */ \
+    /* caller vouches that the boundary entries of w equal those of v already.  _takes: 1 when a call    */ \
+    /* with these sizes would run the one-launch sweeps (else it is mgx3dxs_relax).                      */ \
+    int mgx3dxs_relax_pp_##SFX(mgx_ctx* ctx, real* v, real* w, const real* f, const int n[3],           \
+                               const real h[3], int ncycles, int w_rim_valid);                          \
+    int mgx3dxs_relax_pp_takes_##SFX(const mgx_ctx* ctx, const int n[3], int ncycles);                  \
     int mgx3dxs_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3],     \
                                const real h[3], int mode);                                              \
     int mgx3dxs_restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse,           \

@@ -118,6 +118,8 @@ int mgx_ctx_destroy(mgx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->compute);
     (void)hipStreamSynchronize(ctx->comm);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->sweep_dev) (void)hipFree(ctx->sweep_dev);
+    if (ctx->sweep_abort) (void)hipHostFree(ctx->sweep_abort);
     (void)hipEventDestroy(ctx->ev_compute);
     (void)hipEventDestroy(ctx->ev_comm);
     (void)hipStreamDestroy(ctx->compute);
@@ -131,7 +133,7 @@ int mgx_ctx_sync(mgx_ctx* ctx) {
     MGX_USE(ctx);
     MGX_HIP(hipStreamSynchronize(ctx->compute));
     MGX_HIP(hipStreamSynchronize(ctx->comm));
-    return MGX_OK;
+    return mgx_ctx_check(ctx);
 }
 
 int mgx_ctx_device(const mgx_ctx* ctx, int* device) {

@@ -37,6 +37,12 @@ struct mgx_ctx {
     int cyc2_tile = 0;     // tile edge of the cache-resident 2D cycle kernels: 0 = by level size, 16 / 32 / 64
     int cyc2_tail_points = 33 * 33;  // largest top level (points) handed to the one-workgroup tail kernel of the 2D cycle (measured:
                                      // 65^2 is faster on the tiled kernels, 16 workgroups, than inside the single tail workgroup)
+    int sweep_fused = 0;   // 1: one launch per red+black sweep where the level takes it (mgx_sweep3d.hip); 0 = one per colour (default
+                           // while the one-launch kernel measures slower: DESIGN.md section 5)
+    int sweep_lead = 0;    // planes the red stage of that kernel runs ahead of the black stage (0 = default)
+    int sweep_dbg = 0;     // diagnostic builds: 1 = cycle stamps, + 2 * ablation bits (sweep3d_xs_kernel)
+    void* sweep_dev = nullptr;        // its device state: launch epoch, finished-workgroup counter, progress words
+    unsigned* sweep_abort = nullptr;  // host-mapped word: != 0 once an inter-workgroup wait has given up
     void* scratch = nullptr;  // small device workspace (reductions, tables)
     size_t scratch_bytes = 0;
     void* rccl_comm = nullptr;  // ncclComm_t

@@ -2706,6 +2706,14 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
     return MGX_OK;
 }
 
+// the colour-pass smoother for other translation units (mgx_sweep3d.hip falls back to it)
+template <class real>
+int relax3d_xs_colour_passes(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles) {
+    return relax3d<real, XSplit>(ctx, v, f, n, h, ncycles);
+}
+template int relax3d_xs_colour_passes<float>(mgx_ctx*, float*, const float*, const int[3], const float[3], int);
+template int relax3d_xs_colour_passes<double>(mgx_ctx*, double*, const double*, const int[3], const double[3], int);
+
 }  // namespace mgx
 
 #define MGX_DEFINE_OPS3D(PFX, L, SFX, real)                                                                      \
@@ -2906,6 +2914,17 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "cycle2d.tail_points")) {
         MGX_REQUIRE(value >= 0 && value <= 5120, MGX_ERR_INVALID, "cycle2d.tail_points must be in [0, 5120]");
         ctx->cyc2_tail_points = value;
+    } else if (!strcmp(name, "relax3d.fused")) {
+        ctx->sweep_fused = value ? 1 : 0;  // levels of 513-point rows: one launch per red+black sweep (mgx_sweep3d.hip) or one per colour
+    } else if (!strcmp(name, "relax3d.fused_dbg")) {
+#ifdef MGX_DIAGNOSTICS
+        ctx->sweep_dbg = value;  // 1 = cycle stamps, + 2 * ablation bits: WRONG results
+#else
+        return mgx::fail(MGX_ERR_INVALID, "set_param: 'relax3d.fused_dbg' exists only in diagnostic builds (make diag)");
+#endif
+    } else if (!strcmp(name, "relax3d.fused_lead")) {
+        MGX_REQUIRE(value == 0 || (value >= 5 && value <= 7), MGX_ERR_INVALID, "relax3d.fused_lead (planes the red stage runs ahead) must be 0 (default), 5, 6 or 7");
+        ctx->sweep_lead = value;
     } else if (!strcmp(name, "relax3d.zchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "relax3d.zchunk must be >= 0 (0 = automatic)");
         ctx->relax_zchunk = value;

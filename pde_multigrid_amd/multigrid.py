@@ -251,6 +251,21 @@ class _Ops3D(_Ops):
         h = _rp(grid_spacing(n, rng, dtype), ct)
         return self._run(ctx, [v, f], lambda a, b: fn(ctx._h, a, b, _ip(n), h, C.c_int(ncycles)), 0, _shape(n), dtype)
 
+    def relax_pp(self, ctx, v, f, n, rng, ncycles, w=None, w_rim_valid=False, dtype=None):
+        """x-split only: relax with a ping-pong partner w (one launch per red+black sweep where the level takes it);
+        w defaults to an array of NaNs (its boundary is then copied from v by the call)"""
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("relax_pp", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        if w is None:
+            w = np.full(_shape(n), np.nan, dtype)
+        return self._run(ctx, [v, w, f], lambda a, ww, b: fn(ctx._h, a, ww, b, _ip(n), h, C.c_int(ncycles), C.c_int(int(w_rim_valid))),
+                         0, _shape(n), dtype)
+
+    def relax_pp_takes(self, ctx, n, ncycles, dtype=np.float64):
+        s, _ = _ct(dtype)
+        return bool(getattr(lib, "mgx3dxs_relax_pp_takes_" + s)(ctx._h, _ip(n), C.c_int(ncycles)))
+
     def residual(self, ctx, v, f, n, rng, mode=REF_COMPAT, dtype=None):
         dtype = dtype or v.dtype
         fn, ct = self._fn("residual", dtype)
@@ -416,7 +431,7 @@ def _grid3_struct(ct):
                     ("ctx", C.c_void_p), ("residual_mode", C.c_int), ("fuse", C.c_int), ("layout", C.c_int),
                     ("smoother", C.c_int), ("omega", ct), ("use_graph", C.c_int), ("capturing", C.c_int),
                     ("graph_exec", C.c_void_p * 32), ("graph_key", C.c_longlong * 32), ("f_rim_zero", C.c_ubyte * 32),
-                    ("v_rim_zero", C.c_ubyte * 32)]
+                    ("v_rim_zero", C.c_ubyte * 32), ("e_rim_valid", C.c_ubyte * 32)]
 
     return Grid3D, MultiGrid3D
 
