@@ -77,8 +77,8 @@ __global__ void __launch_bounds__(64 * WX * WY)
                a_nost = DBG && (abl & 16);
     constexpr int TX = 64 * WX, TY = WY * R, NR = D + 1;
     static_assert(D >= 3 && WY >= 2 && R >= 1, "shape");
-    __shared__ real ey[3][WY][WX][2][64];  // three slots: the two halves of the workgroup run half a step apart (below)
-    __shared__ real ex[3][WY][WX][2][R];
+    __shared__ real ey[2][WY][WX][2][64];
+    __shared__ real ex[2][WY][WX][2][R];
     __shared__ real ring[NR][TY][TX];
     const double rd = relax3d_rd<real>(hx2, hy2, hz2);
     const Geo<XSplit, real> g(sx, sy);
@@ -179,17 +179,14 @@ __global__ void __launch_bounds__(64 * WX * WY)
         op[r] = oc[r] = 0;
     }
     MGX_LOAD_RIM(0, q, xc, Nc, Sc);
-    int es_c = zrf % 3, es_n = (zrf + 1) % 3;  // exchange slots of the red planes zr and zr + 1
+    int es_c = zrf & 1, es_n = (zrf + 1) & 1;  // exchange slots of the red planes zr and zr + 1
     publish(es_c, cc);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // The lower half of the waves (wy >= WY / 2) runs HALF A STEP behind the upper half: a step is "issue memory requests |
-    // barrier | arithmetic | barrier", and with all waves in phase the memory pipe idles while everybody computes (measured:
-    // requests are accepted only as fast as memory serves them, so a wave leaves its issue phase with its loads all but
-    // done).  Shifted by one barrier, one half issues while the other computes.  Planes handed over through LDS are
-    // consumed a full step after they were written, so half a step of skew needs only a third exchange slot.
-    const bool late = wy >= WY / 2;
-    if (late) asm volatile("s_barrier" ::: "memory");
+    // (Tried: the lower half of the waves half a step behind the upper half -- "issue | barrier | arithmetic | barrier" with
+    // one half issuing while the other computes, a third exchange slot.  Bit-exact, but 0.90 instead of 0.69 ms per sweep at
+    // 513^3: with four instead of eight waves issuing, a CU has too few bytes in flight and each half's issue phase takes
+    // as long as the whole workgroup's did.  profiles/r03_sweep_stamps.txt)
 
     // ring slots of the planes zr = s + D (written), s (read across lanes) and s + 1 (own entry read)
     int s = z0 - 1 - D;
@@ -294,8 +291,6 @@ __global__ void __launch_bounds__(64 * WX * WY)
         if (red_more) publish(es_n, cu);
         __builtin_amdgcn_s_setprio(0);
         MGX_STAMP(0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        MGX_STAMP(6);
 
         // ---- red stage: plane zr
         if (red_c) {
@@ -380,7 +375,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
             pf += sxy;
             q ^= 1;
             es_c = es_n;
-            es_n = es_n == 2 ? 0 : es_n + 1;
+            es_n ^= 1;
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -395,7 +390,6 @@ __global__ void __launch_bounds__(64 * WX * WY)
         sl_b = sl_b + 1 == NR ? 0 : sl_b + 1;
         sl_u = sl_u + 1 == NR ? 0 : sl_u + 1;
     }
-    if (!late) asm volatile("s_barrier" ::: "memory");  // the barrier the late half is ahead by
     // the last black plane (z1 - 1); the last red plane a run stores (z1 - 1 at most) went out D steps ago
     {
         const int qb0 = (c0 + 1 + y0 + (z1 - 1)) & 1;

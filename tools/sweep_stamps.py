@@ -16,6 +16,7 @@ import pde_multigrid_amd as P  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 513
 lead = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ctx = P.Context(0)
+ctx.set_param("relax3d.fused", 1)
 ctx.set_param("relax3d.fused_lead", lead)
 mg = P.MultiGrid3D(ctx, [n] * 3, [0, 1, 0, 1, 0, 1], np.float64, nlevels=2)
 e0, e1 = ctx.event(), ctx.event()
@@ -32,7 +33,7 @@ def timed(fn, reps=10):
     return sorted(ts[2:])[len(ts[2:]) // 2]
 
 
-NAMES = ["issue", "flagwait", "red", "black", "barrier2", "vmcnt0", "barrier1", "-"]
+NAMES = ["issue", "flagwait", "red", "black", "barrier", "vmcnt0", "-", "-"]
 ABL = [(0, "full"), (1, "no flag waits"), (2, "no sc1"), (3, "no waits, no sc1"), (4, "no black arithmetic"), (8, "no red arithmetic"),
        (12, "no arithmetic"), (16, "no stores"), (31, "nothing but loads + LDS")]
 for bits, name in ABL:
@@ -44,9 +45,9 @@ for bits, name in ABL:
     a = np.frombuffer(buf, dtype=np.int64).reshape(nwg, nw, 8).astype(np.float64)
     tot = a.sum(axis=2)
     print("%-26s Relax(2) %.4f ms = %.4f per sweep; cycles per wave %.0f (min %.0f max %.0f)" % (name, ms, ms / 2, tot.mean(), tot.min(), tot.max()))
-    print("    " + "  ".join("%s %.1f%%" % (NAMES[k], 100 * a[:, :, k].sum() / tot.sum()) for k in range(7)))
+    print("    " + "  ".join("%s %.1f%%" % (NAMES[k], 100 * a[:, :, k].sum() / tot.sum()) for k in range(6)))
     if bits == 0:
         for wv in range(nw):
-            print("      wave %d: " % wv + "  ".join("%s %.1f%%" % (NAMES[k], 100 * a[:, wv, k].sum() / tot[:, wv].sum()) for k in range(7)))
+            print("      wave %d: " % wv + "  ".join("%s %.1f%%" % (NAMES[k], 100 * a[:, wv, k].sum() / tot[:, wv].sum()) for k in range(6)))
 ctx.set_param("relax3d.fused_dbg", 0)
 mg.close()
