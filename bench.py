@@ -4,9 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
 
 N > 1 may be started either by a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
-RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or plainly: without WORLD_SIZE in the environment
-this process only counts the devices (it never initialises the GPU, never imports libmgx and never exec's) and starts
-the N ranks itself as fresh child processes through `python -m torch.distributed.run`, then exits with their code.
+only the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* it puts into the environment are used) or plainly: without WORLD_SIZE
+in the environment this process only counts the devices (it never initialises the GPU, never imports libmgx and never
+exec's), starts the N ranks itself as fresh child processes, watches them and exits with their code.  Either way the
+ranks never import PyTorch: the control plane (the 128-byte ncclUniqueId from rank 0, barriers, the maximum over ranks)
+is pde_multigrid_amd/launch.py, one TCP connection per rank on 127.0.0.1; the data plane is RCCL inside libmgx.
 
 Workload
   N = 1 : BASELINE.json configs[3]: 3D Poisson, 513 points per axis ("512^3"), fp64, native 9-level
@@ -16,6 +18,11 @@ Workload
           all-gather) -- strong scaling: the total work does not depend on N.  `--size` overrides the size.
 One step = one VCycle(0, 2, 2) through the C host layer (include/mg_multigrid.h), inputs resident in HBM.
     MLUPS = (v1+v2) * sum_levels (n_l - 2)^3 * steps / seconds          
+    The K steps are timed BATCHES times (default 5; each batch = exactly K steps between a barrier + sync on both sides,
+    maximum over ranks); `value` / `ms_per_step` are the MEDIAN batch, `batches` lists them all.
+secondary (N = 1, default size only): BASELINE configs[1] (2D Lyapunov 1025^2, 7 levels, fp64), configs[2] (3D 257^3, 6
+    levels, fp64) and the headline workload in the reference's own precision (513^3 fp32), each timed the same way and
+    checked against its committed known answer.
 roofline: the dominant kernel is the red-black Gauss-Seidel smoother on the finest level; its algorithmic
     traffic is 3 reals per lattice update per red+black sweep = 24 B/LUP in fp64 (12 B per LUP of one colour
     launch).  `achieved` = algorithmic bytes per launch / average launch duration, measured here with HIP events
@@ -79,21 +86,19 @@ def known_answer(n, nlev, dtype):
         return json.load(fh).get("3d_n%d_vcycle22_%dlev_%s" % (n, nlev, dtype))
 
 
+def load_launch():
+    """pde_multigrid_amd/launch.py WITHOUT importing the package (its __init__ loads libmgx, which the parent of a plain
+    `bench.py --gpus N` must not do)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgx_launch", os.path.join(ROOT, "pde_multigrid_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def spawn_ranks(args):
     """parent of a plain `bench.py --gpus N`: start the ranks as fresh children BEFORE anything touches the GPU here"""
-    import torch  # device_count() does not initialise the GPU on this image
-    found = torch.cuda.device_count()
-    if found < args.gpus:
-        sys.stderr.write("bench.py: --gpus %d needs %d GPUs, found %d\n" % (args.gpus, args.gpus, found))
-        return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    return load_launch().spawn(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=float(os.environ.get("MGX_BENCH_TIMEOUT", "1500")))
 
 
 def cpu_baseline(args, dtype):
@@ -113,21 +118,21 @@ def cpu_baseline(args, dtype):
 
     have_ref = RS.available("O2") and RS.available("O0")
     # the restatement (same loop nest as the reference, float = the reference's type), both optimisation levels
-    # (legs report seconds per repetition; 2-3 repetitions each keep the whole baseline near 20 s on the GPU box's host)
+    # (legs report seconds per repetition; 3 repetitions of the headline leg, 1 of the others: about 15 s on the GPU box's host)
     leg("port_f32_O2_vcycle257", O.time_vcycle3d(cn, clev, args.v1, args.v2, 3, np.float32, "O2") / 3, c_lups)
-    leg("port_f32_O0_vcycle257", O.time_vcycle3d(cn, clev, args.v1, args.v2, 2, np.float32, "O0") / 2, c_lups)
-    leg("port_f32_O2_relax513", O.time_relax3d(513, 2, np.float32, "O2") / 2, s_lups)
-    leg("port_%s_O2_vcycle257" % args.dtype, O.time_vcycle3d(cn, clev, args.v1, args.v2, 2, dtype, "O2") / 2, c_lups)
+    leg("port_f32_O0_vcycle257", O.time_vcycle3d(cn, clev, args.v1, args.v2, 1, np.float32, "O0"), c_lups)
+    leg("port_f32_O2_relax513", O.time_relax3d(513, 1, np.float32, "O2"), s_lups)
+    leg("port_%s_O2_vcycle257" % args.dtype, O.time_vcycle3d(cn, clev, args.v1, args.v2, 1, dtype, "O2"), c_lups)
     if have_ref:
         value = leg("reference_f32_O2_vcycle257", RS.time_vcycle3d(cn, clev, args.v1, args.v2, 3, "O2") / 3, c_lups)
-        leg("reference_f32_O0_vcycle257", RS.time_vcycle3d(cn, clev, args.v1, args.v2, 2, "O0") / 2, c_lups)
-        leg("reference_f32_O2_relax513", RS.time_relax3d(513, 2, "O2") / 2, s_lups)
-        leg("reference_f32_O0_relax513", RS.time_relax3d(513, 2, "O0") / 2, s_lups)
+        leg("reference_f32_O0_vcycle257", RS.time_vcycle3d(cn, clev, args.v1, args.v2, 1, "O0"), c_lups)
+        leg("reference_f32_O2_relax513", RS.time_relax3d(513, 1, "O2"), s_lups)
+        leg("reference_f32_O0_relax513", RS.time_relax3d(513, 1, "O0"), s_lups)
         kind = "reference"
         what = "the compiled NOCUDA_TESI reference (oracle/_ref, fp32, g++ -O2; the -O0 legs are what its own CompileAndLink builds)"
         ratio = round(legs["port_f32_O2_vcycle257"]["seconds"] / legs["reference_f32_O2_vcycle257"]["seconds"], 3)
     else:
-        leg("port_f32_O0_relax513", O.time_relax3d(513, 2, np.float32, "O0") / 2, s_lups)
+        leg("port_f32_O0_relax513", O.time_relax3d(513, 1, np.float32, "O0"), s_lups)
         value = legs["port_f32_O2_vcycle257"]["mlups"]
         kind = "port"
         what = "the oracle's CPU restatement of the reference (fp32, g++ -O2, reference loop nest)"
@@ -139,6 +144,47 @@ def cpu_baseline(args, dtype):
         "legs": legs,
         "port_over_reference_time": ratio,
     }
+
+
+def run_secondary(P, ctx, np):
+    """BASELINE configs[1], configs[2] and the headline workload in fp32, each: median of 3 batches of cycles from v = 0
+    kept running (as the headline), then ONE cycle from v = 0 checked against the committed known answer"""
+    path = os.path.join(ROOT, "tests", "golden", "known_answers_f64.json")
+    with open(path) as fh:
+        known = json.load(fh)
+    out = {}
+
+    def run(name, key, make, dim, nsz, nlev, steps):
+        mg = make()
+        ka = known.get(key)
+        mg.VCycle(0, 2, 2)
+        ts = []
+        for _ in range(3):
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                mg.VCycle(0, 2, 2)
+            ctx.sync()
+            ts.append((time.perf_counter() - t0) / steps)
+        mg.close()
+        mg = make()  # a fresh hierarchy: the reference's initial state (v = 0; 2D: its boundary values, N2/Grid2D.cpp:50-68)
+        mg.VCycle(0, 2, 2)
+        got = mg.download_v(0)
+        s1, s2 = checksum(got)
+        mg.close()
+        lups = 4 * sum((s - 2) ** dim for s in level_sizes(nsz, nlev))
+        t = sorted(ts)[1]
+        status = "no known answer" if ka is None else ("ok" if ("%016x" % s1, "%016x" % s2) == (ka["sum64"], ka["wsum64"]) else "MISMATCH")
+        out[name] = {"ms_per_cycle": round(t * 1e3, 4), "min_ms": round(min(ts) * 1e3, 4), "mlups": round(lups / t / 1e6, 1),
+                     "steps": steps, "result_check": status, "known_answer": key}
+
+    run("configs[1]: 2D Lyapunov 1025^2, 7 levels, f64, V(2,2)", "2d_n1025_vcycle22_7lev_f64",
+        lambda: P.MultiGrid2D(ctx, [1025] * 2, [0, 1, 0, 1], [-1, -2, 0, -3], 2, np.float64, nlevels=7), 2, 1025, 7, 200)
+    run("configs[2]: 3D Poisson 257^3, 6 levels, f64, V(2,2)", "3d_n257_vcycle22_6lev_f64",
+        lambda: P.MultiGrid3D(ctx, [257] * 3, R3, np.float64, nlevels=6), 3, 257, 6, 50)
+    run("3D Poisson 513^3, 9 levels, f32 (the reference's precision), V(2,2)", "3d_n513_vcycle22_9lev_f32",
+        lambda: P.MultiGrid3D(ctx, [513] * 3, R3, np.float32), 3, 513, 9, 20)
+    return out
 
 
 def main():
@@ -154,6 +200,8 @@ def main():
     ap.add_argument("--min-planes", type=int, default=32,
                     help="N>1: a level stays distributed while every GPU owns this many planes; coarser levels are replicated "
                          "(below about 32 planes per GPU the ghost exchanges are pure latency)")
+    ap.add_argument("--batches", type=int, default=5, help="the K timed steps are repeated this many times; the median batch is reported")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the result check against the committed known answer")
     ap.add_argument("--no-one-gpu-leg", action="store_true", help="N>1: skip rank 0's single-GPU run of the same problem")
@@ -168,16 +216,13 @@ def main():
     if world != args.gpus:
         args.gpus = world
 
-    # MGX_BENCH_FORCE_DIST=1 runs the slab-decomposed code path (torch rendezvous, RCCL communicator, slab
-    # hierarchy) even with one rank: a plumbing check for boxes with a single GPU
+    # MGX_BENCH_FORCE_DIST=1 runs the slab-decomposed code path (rendezvous, RCCL communicator, slab hierarchy) even
+    # with one rank: a plumbing check for boxes with a single GPU
     force_dist = os.environ.get("MGX_BENCH_FORCE_DIST", "0") == "1"
     slabbed = world > 1 or force_dist
-    dist = None
+    rdzv = None
     if slabbed:
-        # torch BEFORE libmgx (pde_multigrid_amd/_lib.py: load order of the ROCm runtime libraries)
-        import torch
-        import torch.distributed as dist  # control plane only (rendezvous, barrier, max over ranks); data plane = RCCL in libmgx
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        rdzv = load_launch().Rendezvous(rank, world)  # control plane: no PyTorch anywhere in a rank
 
     import numpy as np
 
@@ -198,9 +243,8 @@ def main():
         reset = lambda: mg.setToValue_v(0, 0.0, True)  # noqa: E731
         nd = 0
     else:
-        uid = [P.Context.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], rank, world)
+        uid = rdzv.broadcast_bytes(P.Context.unique_id() if rank == 0 else b"", src=0)
+        ctx.comm_init(uid, rank, world)
         mg = P.DistMultiGrid3D(ctx, [n] * 3, R3, dtype, min_planes=args.min_planes)
         reset = lambda: mg.zero_v(0)  # noqa: E731
         nd = mg.numDist
@@ -210,25 +254,29 @@ def main():
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            dist.barrier()
+        if rdzv is not None:
+            rdzv.barrier()
+
+    def timed_batches(cycle, steps, batches):
+        """seconds of `steps` cycles, `batches` times: each batch between barrier + sync on both sides, max over ranks"""
+        out = []
+        for _ in range(batches):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                cycle()
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            out.append(rdzv.max(dt) if rdzv is not None else dt)
+        barrier()
+        return out
 
     # ---- V-cycle throughput -----------------------------------------------------------
     reset()
     for _ in range(args.warmup):
         mg.VCycle(0, args.v1, args.v2)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mg.VCycle(0, args.v1, args.v2)
-    ctx.sync()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    batch_s = timed_batches(lambda: mg.VCycle(0, args.v1, args.v2), args.steps, max(1, args.batches))
+    elapsed = sorted(batch_s)[len(batch_s) // 2]  # the median batch
     mlups = lups_per_cycle * args.steps / elapsed / 1e6  # one shared problem: whole-job rate
 
     # ---- smoother-only region for the roofline (HIP events on the compute stream) -------
@@ -285,8 +333,7 @@ def main():
             if pl.zlo <= n // 2 < pl.zhi:
                 centre = float(got[n // 2 - pl.zlo, n // 2, n // 2])
             if world > 1:
-                parts = [None] * world
-                dist.all_gather_object(parts, (s1, s2, centre))
+                parts = rdzv.all_gather((s1, s2, centre))
                 s1 = sum(q[0] for q in parts) & ((1 << 64) - 1)
                 s2 = sum(q[1] for q in parts) & ((1 << 64) - 1)
                 centre = [q[2] for q in parts if q[2] is not None][0]
@@ -304,14 +351,14 @@ def main():
                     sys.stderr.write("bench.py: RESULT CHECK FAILED -- the cycle's result differs from the oracle's known answer: %s "
                                      "(expected sum64 %s wsum64 %s centre %r); no metric is reported\n"
                                      % (json.dumps(check), ka["sum64"], ka["wsum64"], ka["centre"]))
-    failed = [check is not None and check.get("status") == "MISMATCH"]
-    if dist is not None:
-        dist.broadcast_object_list(failed, src=0)
-    if failed[0]:
+    failed = check is not None and check.get("status") == "MISMATCH"
+    if rdzv is not None:
+        failed = rdzv.broadcast(failed, src=0)
+    if failed:
         mg.close()
         ctx.close()
-        if dist is not None:
-            dist.destroy_process_group()
+        if rdzv is not None:
+            rdzv.close()
         sys.exit(3)
 
     # ---- N > 1: the same problem on ONE GPU (rank 0, the others wait), for the strong-scaling factor ----
@@ -333,7 +380,24 @@ def main():
             one_gpu = {"ms_per_step": round((tb - ta) / k1 * 1e3, 4), "steps": k1,
                        "speedup": round(((tb - ta) / k1) / (elapsed / args.steps), 3),
                        "note": "the same %d^3 hierarchy on rank 0's GPU alone, timed in this run while the other ranks wait" % n}
-        dist.barrier()
+        rdzv.barrier()
+
+    # ---- secondary configurations (N = 1, default workload only) ----
+    secondary = None
+    if world == 1 and not slabbed and not args.no_secondary and n == 513 and args.dtype == "f64" and args.v1 == 2 and args.v2 == 2:
+        secondary = run_secondary(P, ctx, np)
+        if any(c["result_check"] == "MISMATCH" for c in secondary.values()):
+            sys.stderr.write("bench.py: RESULT CHECK FAILED in a secondary configuration: %s; no metric is reported\n" % json.dumps(secondary))
+            mg.close()
+            ctx.close()
+            sys.exit(3)
+
+    comm = None
+    if slabbed:
+        seen, ver = ctx.comm_info()
+        comm = {"ranks_seen": seen, "rccl_version": ver, "launcher": "torch.distributed.run environment" if "MGX_RDZV_KEY" not in os.environ
+                else "bench.py's own children", "control_plane": "pde_multigrid_amd/launch.py (TCP on 127.0.0.1)",
+                "torch_imported": "torch" in sys.modules}
 
     if rank == 0:
         out = {
@@ -344,6 +408,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "batches": {"count": len(batch_s), "ms_per_step": [round(b / args.steps * 1e3, 4) for b in batch_s],
+                        "min": round(min(batch_s) / args.steps * 1e3, 4), "median": round(elapsed / args.steps * 1e3, 4)},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -377,6 +443,10 @@ def main():
         }
         if one_gpu is not None:
             out["config"]["one_gpu_same_problem"] = one_gpu
+        if comm is not None:
+            out["config"]["communicator"] = comm
+        if secondary is not None:
+            out["secondary"] = secondary
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if not slabbed and n == 513 and args.dtype == "f64" and os.path.exists(pmc):
             # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_summary.py): 2 x FETCH_SIZE +
@@ -393,9 +463,9 @@ def main():
         print(json.dumps(out))
     mg.close()
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
 
 
 if __name__ == "__main__":

@@ -157,6 +157,10 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         int norm_count;            /* entries recorded by ResidualNormRecord (<= MG_NORM_HISTORY) */     \
         long long inline_bytes;    /* levels whose slab of v is at most this large exchange inline on the */ \
                                    /* compute stream, one launch per pass (0: always overlapped); public  */ \
+        /* internal: 1 while the boundary entries (and ghost-plane rims) of distributed level l's v are  */ \
+        /* known to be 0: the coarse error then starts a cycle without a zero fill.  Set by create and  */ \
+        /* zero_v, cleared by upload_v.                                                                  */ \
+        unsigned char v_rim_zero[MG_MAX_LEVELS];                                                         \
     } mgDistMultiGrid3D_##R;                                                                             \
     int mgDistMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6], \
                                        int min_planes, mgDistMultiGrid3D_##R** out);                     \

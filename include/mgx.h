@@ -359,6 +359,8 @@ int mgx_comm_unique_id(void* host_id_bytes);
 int mgx_comm_init(mgx_ctx* ctx, const void* host_id_bytes, int rank, int nranks);
 int mgx_comm_destroy(mgx_ctx* ctx);
 int mgx_comm_rank(const mgx_ctx* ctx, int* rank, int* nranks);
+/* the number of ranks the communicator itself reports (ncclCommCount) and the RCCL version in use (ncclGetVersion) */
+int mgx_comm_info(const mgx_ctx* ctx, int* ranks_seen, int* rccl_version);
 /* Test transport: `nranks` host threads of one process, one context each, all on the same device, so that the
  * slab-decomposed cycle AND the event ordering of its overlap schedule can be verified on a single-GPU box.  Same
  * stream semantics as RCCL: an exchange only enqueues device-to-device copies on the comm stream, ordered against

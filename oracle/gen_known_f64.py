@@ -54,6 +54,31 @@ def case(n, dtype=np.float64):
     }
 
 
+def case_levels(n, nlev, dtype):
+    """3D, explicit level count (BASELINE configs[2]: 257^3 with 6 levels)"""
+    v = O.cycle3d([n] * 3, R3, nlevels=nlev, mode=0, v1=2, v2=2, reps=1, dtype=dtype)
+    s1, s2 = checksum64(v)
+    return {"n": n, "nlevels": nlev, "v1": 2, "v2": 2, "dtype": "f64" if dtype == np.float64 else "f32", "fnv": O.fnv(v),
+            "sum64": s1, "wsum64": s2, "centre": float(v[n // 2, n // 2, n // 2])}
+
+
+def case2d(n, nlev, dtype):
+    """2D Lyapunov (BASELINE configs[1]: 1025^2, 7 levels; the reference driver's A, alfa, N2/LyapunovSolver.cpp:13-28, unit box)"""
+    v = O.cycle2d([n] * 2, [0, 1, 0, 1], [-1.0, -2.0, 0.0, -3.0], 2, nlevels=nlev, mode=0, v1=2, v2=2, reps=1, dtype=dtype)
+    s1, s2 = checksum64(v)
+    return {"n": n, "nlevels": nlev, "v1": 2, "v2": 2, "dtype": "f64" if dtype == np.float64 else "f32", "fnv": O.fnv(v),
+            "sum64": s1, "wsum64": s2, "centre": float(v[n // 2, n // 2])}
+
+
+def secondary(data):
+    """the configurations bench.py reports under `secondary` (keys carry the level count and the type)"""
+    for dt, t in (("f64", np.float64), ("f32", np.float32)):
+        data["3d_n257_vcycle22_6lev_%s" % dt] = case_levels(257, 6, t)
+        data["2d_n1025_vcycle22_7lev_%s" % dt] = case2d(1025, 7, t)
+        for k in ("3d_n257_vcycle22_6lev_%s" % dt, "2d_n1025_vcycle22_7lev_%s" % dt):
+            print(k, data[k]["fnv"], data[k]["centre"], flush=True)
+
+
 def main():
     """arguments: sizes, each optionally suffixed with the type, e.g. `513 1025 513:f32` (default f64).  fp32 cases are
     restatement<float>, which is bit-identical to the compiled reference (tests/test_oracle_vs_ref.py)"""
@@ -62,6 +87,11 @@ def main():
     if os.path.exists(OUT):
         with open(OUT) as fh:
             data = json.load(fh)
+    if todo == [["secondary"]]:
+        secondary(data)
+        with open(OUT, "w") as fh:
+            json.dump(data, fh, indent=1, sort_keys=True)
+        return
     for t in todo:
         n, dt = int(t[0]), (t[1] if len(t) > 1 else "f64")
         key = "3d_n%d_vcycle22_%dlev_%s" % (n, O.num_grids(n), dt)

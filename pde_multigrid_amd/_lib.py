@@ -6,8 +6,9 @@ module raises ImportError, and every call that needs a device returns MGX_ERR_NO
 
 Load order: PyTorch-ROCm bundles its own copies of libamdhip64 / librccl (same sonames as /opt/rocm's).
 A process that uses both must import torch BEFORE this module, so that libmgx binds to the copies torch
-loaded; the opposite order mixes two ROCm runtimes and aborts at exit.  bench.py (N > 1) and the gloo
-test workers do that; everything else never imports torch.
+loaded; the opposite order mixes two ROCm runtimes and aborts at exit.  Only the gloo test workers (CPU emulation of
+the slab schedule) do that; bench.py's ranks and everything else never import torch (pde_multigrid_amd/launch.py is the
+control plane of N > 1 runs), so the data plane runs on the ROCm runtime and RCCL libmgx was built with.
 """
 import ctypes as C
 import os

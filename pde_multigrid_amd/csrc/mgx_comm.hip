@@ -41,7 +41,7 @@ static_assert(sizeof(ncclUniqueId) == MGX_UNIQUE_ID_BYTES, "MGX_UNIQUE_ID_BYTES 
 
 // shared state of a local (in-process) group
 struct mgx_local_group {
-    static constexpr int SLOTS = 2;  // event ring: exchange k uses slot k % SLOTS (see the reuse argument in local_begin)
+    static constexpr int SLOTS = 3;  // event ring: exchange k uses slot k % SLOTS (see the reuse argument in local_begin)
     int nranks = 0;
     std::mutex mu;
     std::condition_variable cv;
@@ -104,7 +104,13 @@ __global__ void __launch_bounds__(256) sum_ranks_kernel(const double* __restrict
 //      like ncclSend, the exchange is complete on my comm stream only when my planes have been received.
 // Event reuse: ready[r][s] is re-recorded in collective k + SLOTS; every wait on its k-th recording was issued
 // in step 2 of a peer's collective k, which precedes that peer's posted_done = k, which rank r has seen in step 4
-// of its own collective k.  The same argument covers done[][] and the posted pointers.
+// of its own collective k.  The same argument covers the posted pointers, and done[r][s] as far as the peers of
+// collective k + SLOTS are concerned.  Consecutive collectives may have different peer sets, though (all-gather:
+// everybody; halo exchange: the chain neighbours): a rank p that was a peer of r in collective k but is none in the
+// following halo exchanges may issue its step-4 wait on done[r][s] after r has re-recorded the event for collective
+// k + SLOTS.  p then waits for the newer recording, which lies later in r's stream: it over-waits, it never sees an
+// earlier state, and it cannot form a cycle (r's collective k + SLOTS does not involve p, so it does not wait for p).
+// Three slots make that case rarer; they are not what makes it correct.
 struct Peers {
     int p[64];
     int n = 0;
@@ -181,6 +187,16 @@ Peers all_peers(const mgx_ctx* ctx) {
     return p;
 }
 
+// a rank that bails out between local_begin and local_end tells the others, so that they fail at once instead of
+// waiting for the rendezvous timeout
+void local_fail(mgx_local_group* g) {
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->failed = true;
+    }
+    g->cv.notify_all();
+}
+
 int local_halo(mgx_ctx* ctx, const void* send_lo, void* recv_lo, size_t n_from_lo, const void* send_up, void* recv_up,
                size_t n_from_up, int eb) {
     mgx_local_group* g = (mgx_local_group*)ctx->local_group;
@@ -190,11 +206,13 @@ int local_halo(mgx_ctx* ctx, const void* send_lo, void* recv_lo, size_t n_from_l
     const int s = (int)(k % mgx_local_group::SLOTS);
     if (ctx->rank > 0 && n_from_lo) {
         const void* src = g->rank[ctx->rank - 1].to_upper[s];
+        if (!src) local_fail(g);
         MGX_REQUIRE(src, MGX_ERR_INVALID, "halo exchange: the lower neighbour sends nothing up, but %zu elements are expected", n_from_lo);
         MGX_HIP(hipMemcpyAsync(recv_lo, src, n_from_lo * eb, hipMemcpyDeviceToDevice, cstream(ctx)));
     }
     if (ctx->rank < ctx->nranks - 1 && n_from_up) {
         const void* src = g->rank[ctx->rank + 1].to_lower[s];
+        if (!src) local_fail(g);
         MGX_REQUIRE(src, MGX_ERR_INVALID, "halo exchange: the upper neighbour sends nothing down, but %zu elements are expected", n_from_up);
         MGX_HIP(hipMemcpyAsync(recv_up, src, n_from_up * eb, hipMemcpyDeviceToDevice, cstream(ctx)));
     }
@@ -322,13 +340,15 @@ int mgx_comm_init_local(mgx_ctx* ctx, mgx_local_group* group, int rank) {
 int mgx_comm_destroy(mgx_ctx* ctx) {
     MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
     MGX_USE(ctx);
+    // inline mode enqueues collectives on the compute stream: both streams may hold operations of the communicator
+    (void)hipStreamSynchronize(ctx->compute);
+    (void)hipStreamSynchronize(ctx->comm);
     if (ctx->rccl_comm) {
-        (void)hipStreamSynchronize(ctx->comm);
         ncclCommDestroy((ncclComm_t)ctx->rccl_comm);
         ctx->rccl_comm = nullptr;
     }
-    if (ctx->local_group) (void)hipStreamSynchronize(ctx->comm);
     ctx->local_group = nullptr;
+    ctx->comm_inline = 0;  // a communicator initialised later starts in overlapped mode
     ctx->rank = 0;
     ctx->nranks = 1;
     return MGX_OK;
@@ -338,6 +358,22 @@ int mgx_comm_rank(const mgx_ctx* ctx, int* rank, int* nranks) {
     MGX_REQUIRE(ctx && rank && nranks, MGX_ERR_INVALID, "NULL argument");
     *rank = ctx->rank;
     *nranks = ctx->nranks;
+    return MGX_OK;
+}
+
+// what the communicator itself reports: the number of ranks RCCL sees (ncclCommCount; the local test transport: its
+// group size; no communicator: 1) and the RCCL version the library is running on (ncclGetVersion, e.g. 22105)
+int mgx_comm_info(const mgx_ctx* ctx, int* ranks_seen, int* rccl_version) {
+    MGX_REQUIRE(ctx && ranks_seen && rccl_version, MGX_ERR_INVALID, "NULL argument");
+    *ranks_seen = ctx->nranks;
+    *rccl_version = 0;
+    int v = 0;
+    if (ncclGetVersion(&v) == ncclSuccess) *rccl_version = v;
+    if (ctx->rccl_comm) {
+        int n = 0;
+        MGX_NCCL(ncclCommCount((ncclComm_t)ctx->rccl_comm, &n));
+        *ranks_seen = n;
+    }
     return MGX_OK;
 }
 

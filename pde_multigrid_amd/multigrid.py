@@ -123,6 +123,12 @@ class Context:
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         check(lib.mgx_comm_init(self._h, buf, int(rank), int(nranks)))
 
+    def comm_info(self):
+        """(ranks the communicator reports, RCCL version code)"""
+        n, v = C.c_int(0), C.c_int(0)
+        check(lib.mgx_comm_info(self._h, C.byref(n), C.byref(v)))
+        return n.value, v.value
+
     def comm_set_inline(self, on):
         """collectives on the compute stream (True) or on the comm stream (False): mgx_comm_set_inline"""
         check(lib.mgx_comm_set_inline(self._h, C.c_int(int(bool(on)))))
@@ -760,7 +766,7 @@ def _dist_struct(ct):
         _fields_ = [("slabs", C.POINTER(C.POINTER(Slab3D))), ("numDist", C.c_int), ("numGrids", C.c_int), ("maxGrids", C.c_int),
                     ("tail", C.c_void_p), ("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
                     ("residual_mode", C.c_int), ("d_share", C.c_void_p), ("d_bplane", C.c_void_p), ("d_norm", C.c_void_p),
-                    ("norm_count", C.c_int), ("inline_bytes", C.c_longlong)]
+                    ("norm_count", C.c_int), ("inline_bytes", C.c_longlong), ("v_rim_zero", C.c_ubyte * 32)]
 
     return Slab3D, DistMultiGrid3D
 

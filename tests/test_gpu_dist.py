@@ -23,7 +23,7 @@ DELAY_US = 300  # a colour pass of these grids takes 5-50 us: every transfer arr
 
 
 def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COMPAT, v0=None, f0=None, nlevels=0, fmg=0,
-              delay_us=DELAY_US, drop_waits=False, extra=None, join_timeout=100, inline_bytes=0):
+              delay_us=DELAY_US, drop_waits=False, extra=None, join_timeout=100, inline_bytes=0, v_levels=None):
     """inline_bytes = 0: every level runs the OVERLAPPED schedule (comm stream, edge planes first) -- what these tests were
     written for; None: the library default (small levels exchange inline on the compute stream); a number: that threshold"""
     ctxs = [P.Context(0) for _ in range(nranks)]
@@ -43,6 +43,8 @@ def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COM
                 mg.upload_f(0, f0)
             if v0 is not None:
                 mg.upload_v(0, v0)
+            for lvl, arr in (v_levels or {}).items():
+                mg.upload_v(lvl, arr)
             if fmg:
                 mg.FullMultiGridVCycle(0, fmg, v1, v2)
             for _ in range(cycles):
@@ -76,6 +78,22 @@ def test_dist_vcycle_matches_single_gpu_and_oracle(nranks, n, min_planes):
     assert info[0][0] == P.dist_num_levels(n, nranks, O.num_grids(n), min_planes) >= 1
     want = O.cycle3d([n] * 3, R3, mode=0, v1=2, v2=2, reps=2, dtype=np.float64)
     assert not np.isnan(got).any()
+    assert bits_equal(got, want)
+
+
+@pytest.mark.timeout(150)
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_dist_coarse_level_v_with_nonzero_boundary_is_zeroed(nranks):
+    """The cycle zeroes the coarse v INCLUDING its boundary (setToValue(v, 0, true), N3/MultiGrid3D.cpp:634).  The slab
+    driver normally skips the fill (the first red pass does not read v) and relies on the boundary being zero in
+    memory; a v uploaded into a coarse distributed level breaks that premise and must bring the fill back."""
+    n3 = [65, 65, 65]
+    rng = np.random.default_rng(7)
+    f0 = rng.uniform(-1, 1, O.shape(n3)).astype(np.float64)
+    junk = rng.uniform(-1, 1, O.shape([33] * 3)).astype(np.float64)  # boundary entries included
+    got, info = run_ranks(nranks, n3, R3, np.float64, 2, 2, 2, 4, f0=f0, v_levels={1: junk})
+    assert info[0][0] >= 2, "level 1 must be a distributed level for this test"
+    want = O.cycle3d(n3, R3, mode=0, v1=2, v2=2, reps=2, f=f0, dtype=np.float64)
     assert bits_equal(got, want)
 
 
