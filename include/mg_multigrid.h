@@ -130,9 +130,16 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
     /* solve(grid, rhs, nlevels): host arrays in the reference layout; grid = initial guess incl.     */ \
     /* boundary values on input, solution on output; nlevels = 0 -> reference rule; ncycles V(v1,v2)  */ \
     /* cycles from the given guess, or one FullMultiGridVCycle(v0,v1,v2) when fmg != 0.               */ \
+    /* rhs == NULL: the reference's own right-hand side (Grid3D::InitF) is built on the device, nothing is  */ \
+    /* uploaded for it.  grid_is_zero != 0 (mg3d_solve_from_zero): the guess is the reference's InitV state */ \
+    /* (all zeros); `grid` is output only and no guess is uploaded either -- with both, the call is the     */ \
+    /* reference's whole driver (N3/Poisson3DSolver.cpp:6-51) with ONE transfer, the result.               */ \
     int mg3d_solve_##R(mgx_ctx* ctx, real* grid, const real* rhs, const int sizeXYZ[3],                  \
                        const real range[6], int nlevels, int fmg, int v0, int v1, int v2, int ncycles,   \
                        int residual_mode);                                                               \
+    int mg3d_solve_from_zero_##R(mgx_ctx* ctx, real* grid_out, const real* rhs, const int sizeXYZ[3],    \
+                                 const real range[6], int nlevels, int fmg, int v0, int v1, int v2,      \
+                                 int ncycles, int residual_mode);                                        \
     /* ---- z-slab decomposed 3D V-cycle (one process per GPU; csrc/host/mg_dist3d.inc) ---- */         \
     typedef struct mgSlab3D_##R {                                                                        \
         real* d_v; /* local planes [zoff, zoff+nzl) of the level, x-split layout, ghosts included */     \

@@ -340,6 +340,9 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx2d_jacobi_##SFX(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[2],             \
                            const real h[2], const real a[2], const real A[4], int alfa, real omega,     \
                            int ncycles);                                                                \
+    /* init_v: Grid2D::InitV (N2/Grid2D.cpp:50-68) on the device: boundary 2*xj*xj-4*xj*yi+2*yi*yi with   */ \
+    /* xj = a[0] + x*h[0], yi = a[1] + y*h[1] in `real`, interior 0; bit-identical to the host loop      */ \
+    int mgx2d_init_v_##SFX(mgx_ctx* ctx, real* v, const int n[2], const real h[2], const real a[2]);    \
     int mgx2d_mean_abs_error_##SFX(mgx_ctx* ctx, const real* v, const int n[2], const real h[2],        \
                                    const real a[2], double* host_mean);                                 \
     int mgx_norm2_##SFX(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq);

@@ -426,7 +426,7 @@ int mgx_comm_wait(mgx_ctx* ctx) {
 // Inline mode: collectives are enqueued on the compute stream, in order with the kernels, instead of on the comm stream
 // behind an event -- no overlap with computation, but also none of the two cross-stream dependencies an overlapped
 // exchange costs (measured 12.5 us each on MI355X / ROCm 7.2 against 2.5 us between kernels of one stream,
-// tools/debug/hop_latency.hip): the right mode for levels whose interior pass is shorter than that.  Switching it on first
+// tools/probes/hop_latency.hip): the right mode for levels whose interior pass is shorter than that.  Switching it on first
 // orders the compute stream behind whatever the comm stream still holds (one communicator: its operations stay in one
 // order on every rank); every rank must switch at the same points of its schedule.
 int mgx_comm_set_inline(mgx_ctx* ctx, int on) {

@@ -245,6 +245,23 @@ __global__ void __launch_bounds__(256) abs_error2d_kernel(const real* __restrict
     }
 }
 
+// Grid2D::InitV on the device: boundary = 2*xj*xj-4*xj*yi+2*yi*yi, interior 0.           N2/Grid2D.cpp:50-68
+// (kernel inventory of the CUDA twin: CUDASetBoundaries, C2/Grid2D.cu:159-182).  Only * and + / - in `real`, evaluated
+// left to right as the reference's expression is ((2*xj)*xj - (4*xj)*yi) + (2*yi)*yi, no contraction: bit-identical to the
+// host loop without any libm policy.
+template <class real>
+__global__ void __launch_bounds__(256) init_v2d_kernel(real* __restrict__ v, int sx, int sy, real hx, real hy, real ax, real ay) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= sx || y >= sy) return;
+    real out = 0;
+    if (x == 0 || x == sx - 1 || y == 0 || y == sy - 1) {
+        const real yi = ay + y * hy;
+        const real xj = ax + x * hx;
+        out = 2 * xj * xj - 4 * xj * yi + 2 * yi * yi;  // :61
+    }
+    v[x + (size_t)y * sx] = out;
+}
+
 // =========================================================================== cache-resident cycle kernels
 // At BASELINE's 1025^2 the hierarchy (22 MB in fp64) never leaves L2 / Infinity Cache, so the cycle is bound by the number
 // of launches and by cache latency, not by HBM: one launch per colour pass per level costs ~60 launches per V(2,2).
@@ -804,6 +821,18 @@ int mean_abs_error2d(mgx_ctx* ctx, const real* v, const int n[2], const real h[2
     return MGX_OK;
 }
 
+template <class real>
+int init_v2d(mgx_ctx* ctx, real* v, const int n[2], const real h[2], const real a[2]) {
+    MGX_REQUIRE(ctx && v && h && a, MGX_ERR_INVALID, "init_v2d: NULL argument");
+    MGX_USE(ctx);
+    int st = check_n2(n, "init_v2d");
+    if (st) return st;
+    hipLaunchKernelGGL((init_v2d_kernel<real>), dim3(ceil_div(n[0], 64), ceil_div(n[1], 4)), dim3(64, 4, 1), 0, ctx->compute, v, n[0], n[1],
+                       h[0], h[1], a[0], a[1]);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
 // ---- host side of the cache-resident cycle kernels ------------------------------------------------------------------
 template <class K>
 static int allow_lds(K kernel, size_t bytes) {  // dynamic LDS beyond the 64 KB default needs the attribute (160 KB per CU)
@@ -982,6 +1011,9 @@ int cycle2d_tail(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const i
         for (int l = 0; l < nlev; l++) e += (size_t)2 * n[2 * l] * n[2 * l + 1];                                  \
         return e * sizeof(real) <= 150 * 1024;                                                                    \
     }                                                                                                             \
+    int mgx2d_init_v_##SFX(mgx_ctx* ctx, real* v, const int n[2], const real h[2], const real a[2]) {            \
+        return mgx::init_v2d<real>(ctx, v, n, h, a);                                                             \
+    }                                                                                                            \
     int mgx2d_mean_abs_error_##SFX(mgx_ctx* ctx, const real* v, const int n[2], const real h[2], const real a[2], \
                                    double* host_mean) {                                                          \
         return mgx::mean_abs_error2d<real>(ctx, v, n, h, a, host_mean);                                          \

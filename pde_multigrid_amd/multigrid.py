@@ -883,6 +883,19 @@ def solve3d(ctx, grid, rhs, rng, nlevels=0, fmg=False, v0=1, v1=2, v2=2, ncycles
     return grid
 
 
+def solve3d_from_zero(ctx, n, rng, dtype=np.float64, rhs=None, nlevels=0, fmg=False, v0=1, v1=2, v2=2, ncycles=1,
+                      residual_mode=REF_COMPAT):
+    """mg3d_solve_from_zero: the guess is the reference's InitV state (zeros, nothing uploaded); rhs=None: the reference's
+    own right-hand side, built on the device -- then the only transfer of the call is the result"""
+    s, ct = _ct(dtype)
+    out = np.empty(_shape(n), dtype)
+    r = np.ascontiguousarray(rhs, dtype).ctypes.data_as(C.c_void_p) if rhs is not None else None
+    check(getattr(lib, "mg3d_solve_from_zero_" + s)(ctx._h, out.ctypes.data_as(C.c_void_p), r, _ip(n), _rp(rng, ct), C.c_int(nlevels),
+                                                    C.c_int(int(fmg)), C.c_int(v0), C.c_int(v1), C.c_int(v2), C.c_int(ncycles),
+                                                    C.c_int(residual_mode)))
+    return out
+
+
 def solve2d(ctx, grid, rhs, rng, A, alfa, nlevels=0, fmg=False, v0=1, v1=2, v2=2, ncycles=1):
     grid = np.ascontiguousarray(grid).copy()
     s, ct = _ct(grid.dtype)

@@ -816,6 +816,36 @@ def test_jacobi_vcycle_converges_and_diff_stats(ctx):
     mg.close()
 
 
+def test_3d_solve_from_zero_is_the_reference_driver(ctx, known_answers):
+    """mg3d_solve_from_zero with rhs = NULL: construct, InitF on the device, FMG, download -- N3/Poisson3DSolver.cpp:6-51
+    with one transfer; fp32 against the compiled reference's known answer, fp64 with an uploaded rhs against the oracle"""
+    got = P.solve3d_from_zero(ctx, [17] * 3, R3, np.float32, fmg=True, v0=1, v1=2, v2=2)
+    assert O.fnv(got) == known_answers["3d_n17_fmg122"]["hash"]
+    got = P.solve3d_from_zero(ctx, [33] * 3, R3, np.float32, ncycles=1)
+    assert O.fnv(got) == known_answers["3d_n33_vcycle22"]["hash"]
+    n3, rg = [33, 17, 65], [-1, 1, 0, 2, 0.5, 3]
+    f = np.random.default_rng(3).uniform(-1, 1, O.shape(n3))
+    got = P.solve3d_from_zero(ctx, n3, rg, np.float64, rhs=f, ncycles=2)
+    assert_f64(got, O.cycle3d(n3, rg, mode=0, v1=2, v2=2, reps=2, f=f, dtype=np.float64))
+
+
+def test_2d_initv_on_the_device(ctx):
+    """Grid2D::InitV (N2/Grid2D.cpp:50-68) as a kernel: fp32 against the reference's own values, every level, fp64 and an
+    anisotropic box with negative coordinates against the oracle"""
+    g = load_golden("init2d_n33.npz")
+    mg = P.MultiGrid2D(ctx, [33, 33], [0, 1, 0, 1], A2, 2, np.float32)
+    assert bits_equal(mg.download_v(0), g["v"]) and bits_equal(mg.download_f(0), g["f"])
+    for lvl in range(1, mg.numGrids):
+        assert bits_equal(mg.download_v(lvl), O.init2d([33, 33], [0, 1, 0, 1], lvl)[0])
+    mg.close()
+    for dtype in (np.float32, np.float64):
+        n2, rg = [129, 33], [-1.5, 2, 0.25, 3]
+        mg = P.MultiGrid2D(ctx, n2, rg, A2, 2, dtype)
+        for lvl in range(mg.numGrids):
+            assert bits_equal(mg.download_v(lvl), O.init2d(n2, rg, lvl, dtype=dtype)[0])
+        mg.close()
+
+
 def test_2d_mean_absolute_error_metric(ctx):
     """the thesis' accuracy metric (Fig. 4.3; PrintMeanAbsoluteError, C2/Grid2D.cu:123-154) on the device"""
     n = 129

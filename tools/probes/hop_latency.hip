@@ -1,5 +1,5 @@
 // cross-stream dependency latency: kernel on s1 -> event -> s2 waits -> kernel on s2 -> event -> s1 waits ...
-// build: hipcc --offload-arch=gfx950 -O2 -o tools/debug/hop_latency tools/debug/hop_latency.hip
+// build: hipcc --offload-arch=gfx950 -O2 -o tools/probes/hop_latency tools/probes/hop_latency.hip
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

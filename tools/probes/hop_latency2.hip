@@ -1,5 +1,5 @@
 // cross-stream dependency through stream memory operations (hipStreamWriteValue32 / hipStreamWaitValue32) instead of events
-// build: hipcc --offload-arch=gfx950 -O2 -o tools/debug/hop_latency2 tools/debug/hop_latency2.hip
+// build: hipcc --offload-arch=gfx950 -O2 -o tools/probes/hop_latency2 tools/probes/hop_latency2.hip
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
