@@ -286,6 +286,22 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx3dxs_interpolate_correct_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3],   \
                                                 const real h[3], const real* coarse_v, const int cn[3], \
                                                 int ncycles);                                           \
+    /* The same on a z-slab (the post-smoothing of the slab-decomposed cycle), in its two pieces.  n / cn */ \
+    /* are GLOBAL sizes, v / f start at global plane fzoff (even), coarse_v at global plane czoff and     */ \
+    /* holds cplanes planes.  corr_fused_takes: 1 when a level with these rows and `nplanes` planes to    */ \
+    /* update runs the on-the-fly form.  correct_pset_slab: the tile-edge cells ("set P") of the GLOBAL   */ \
+    /* fine planes [zmin, zmax) get v += Interpolate(coarse_v) in place (black points) -- list the ghost  */ \
+    /* planes next to the updated range too, the red pass reads them.  relax_corr_colour_slab: the RED    */ \
+    /* pass over the LOCAL planes [zbeg, zend), every other black value read through the correction; the  */ \
+    /* black pass that must follow rewrites every black interior point.                                  */ \
+    int mgx3dxs_corr_fused_takes_##SFX(const mgx_ctx* ctx, const int n[3], int nplanes);                \
+    int mgx3dxs_correct_pset_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff,               \
+                                        const real* coarse_v, const int cn[3], int czoff, int zmin,     \
+                                        int zmax);                                                      \
+    int mgx3dxs_relax_corr_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3],      \
+                                             int fzoff, const real h[3], const real* coarse_v,          \
+                                             const int cn[3], int czoff, int cplanes, int zbeg,         \
+                                             int zend);                                                 \
     /* _colour forms: only the points with (x + y + z_global) % 2 == colour are corrected (-1 = all).  */ \
     /* The cycle passes colour 1 (black) when red-black sweeps follow: the red pass rewrites every red */ \
     /* interior point from black neighbours alone, so a corrected red value is never read.            */ \

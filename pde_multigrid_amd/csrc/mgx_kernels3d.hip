@@ -391,6 +391,9 @@ __global__ void __launch_bounds__(64 * WX * WY)
 // Loads and stores therefore have the whole step (LDS traffic, ~40 fp64 operations per point, the barrier) to
 // complete, and a wave has memory requests in flight all the time instead of only while it waits for them.
 //
+// (CORR on a z-slab: vin / f / vout and `coarse` are local arrays; the host shifts `coarse` so that local fine plane z
+// interpolates from coarse planes z >> 1 (+1), hands in szg = global plane count - global index of local plane 0, and
+// ckmax = the last coarse plane (in that indexing) that exists locally: staging requests are clamped to it.)
 // VAR = 2 ("CORR"): the pass reads the other colour THROUGH the coarse-grid correction -- every own-column value of the
 // other colour that enters the registers gets e = Interpolate(coarse)(x, y, z) added if it is an interior point: exactly
 // what Interpolate + ApplyCorrection (N3/MultiGrid3D.cpp:638-642) would have stored there.  The first red pass of the
@@ -417,7 +420,7 @@ template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0>
 __global__ void __launch_bounds__(64 * WX * WY)
     relax3d_xs_pipe_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                            int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
-                           int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0) {
+                           int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0, int ckmax = 0) {
     constexpr bool CORR = VAR == 2;
     const double rd = relax3d_rd<real>(hx2, hy2, hz2);  // fp32: the division by multiplication (relax3d_point_rd)
     static_assert(!CORR || R == 2, "the correcting variant is written for 2 rows per lane");
@@ -584,12 +587,12 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 if (z0 + 1 <= szg - 2 && (qr | j)) cu[r] = cu[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + qr, y, z0 + 1);
             }
         // the coarse planes under the arrivals of the first three steps (the loop's requests start with the fourth)
-        MGX_K_REQUEST((z0 + 2) >> 1);
+        MGX_K_REQUEST(min((z0 + 2) >> 1, ckmax));
         MGX_K_STORE((z0 + 2) >> 1);
-        MGX_K_REQUEST(min(((z0 + 2) >> 1) + 1, (szg - 1) >> 1));
+        MGX_K_REQUEST(min(((z0 + 2) >> 1) + 1, ckmax));
         MGX_K_STORE(((z0 + 2) >> 1) + 1);
         if (z0 & 1) {
-            MGX_K_REQUEST(min(((z0 + 2) >> 1) + 2, (szg - 1) >> 1));
+            MGX_K_REQUEST(min(((z0 + 2) >> 1) + 2, ckmax));
             MGX_K_STORE(((z0 + 2) >> 1) + 2);
         }
     }
@@ -615,7 +618,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 // coarse planes (s + 2) >> 1 and, for odd s, (s + 3) / 2: that one is requested in step s - 3 (these are
                 // the LAST loads of the step: they stay in flight over the step's end), stored at the end of step s - 2
                 // and so visible from the barrier of step s - 1 on
-                if (!(z & 1) && z + 4 < z1) MGX_K_REQUEST(min((z >> 1) + 3, (szg - 1) >> 1));
+                if (!(z & 1) && z + 4 < z1) MGX_K_REQUEST(min((z >> 1) + 3, ckmax));
             }
             publish((z + 1) & 1, cu);
         }
@@ -1217,10 +1220,12 @@ __global__ void __launch_bounds__(256) interpolate3d_kernel(real* __restrict__ f
 // COLOUR >= 0: only the fine points with (x + y + z) % 2 == COLOUR are written (the half-row of that parity in
 // every row).  The cycle uses COLOUR = 1 when a red-black sweep follows: the red pass overwrites every red interior
 // point from black neighbours only, so a corrected red value would never be read.
+// [zmin, zmax): the global fine planes that may be written (a slab's ghost planes: the cell's other plane, and the coarse
+// plane only it needs, may lie outside the local arrays)
 template <class real, bool ADD, int COLOUR>
 __device__ __forceinline__ void interp_cell_xs(real* __restrict__ fine, const Geo<XSplit, real>& gf, int fzoff,
                                                const real* __restrict__ coarse, const Geo<XSplit, real>& gc, int czoff, int i, int py,
-                                               int pz) {
+                                               int pz, int zmin = 1, int zmax = 0x7fffffff) {
     const int FH = gf.H, CH = gc.H;
     const size_t cxy = gc.PL, fxy = gf.PL;
     real c[2][2][2];
@@ -1230,12 +1235,14 @@ __device__ __forceinline__ void interp_cell_xs(real* __restrict__ fine, const Ge
         for (int dy = 0; dy < 2; dy++)
 #pragma unroll
             for (int dx = 0; dx < 2; dx++)
-                c[dx][dy][dz] = coarse[XSplit::pos(i + dx, CH) + (size_t)(py + dy) * gc.P + (size_t)(pz + dz - czoff) * cxy];
+                c[dx][dy][dz] = (dz == 0 || 2 * pz + 1 < zmax)
+                                    ? coarse[XSplit::pos(i + dx, CH) + (size_t)(py + dy) * gc.P + (size_t)(pz + dz - czoff) * cxy]
+                                    : (real)0;
     auto get = [&](int dx, int dy, int dz) { return c[dx][dy][dz]; };
 #pragma unroll
     for (int dz = 0; dz < 2; dz++) {
         const int z = 2 * pz + dz;
-        if (z < 1) continue;
+        if (z < 1 || z < zmin || z >= zmax) continue;
 #pragma unroll
         for (int dy = 0; dy < 2; dy++) {
             const int y = 2 * py + dy;
@@ -1269,12 +1276,15 @@ __global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict_
 // the two fine rows a workgroup tile of the correcting pass sees just outside itself and, from the neighbouring tile's
 // point of view, its own first / last row) or i % PW in {0, PW - 1}, i > 0 (part 1: the pairs next to a tile's left /
 // right edge; cells of part 0 are skipped there) get v += Interpolate(coarse) in place before the pass runs.
+// Slab form: fine / coarse are local arrays starting at the global planes fzoff / czoff, the cells pzbeg ... are visited and
+// only the global fine planes [zmin, zmax) are written.
 template <class real>
 __global__ void __launch_bounds__(256) correct_pset3d_xs_kernel(real* __restrict__ fine, int fx, int fy, const real* __restrict__ coarse,
-                                                                int cx, int cy, int PW, int PH, int part) {
+                                                                int cx, int cy, int PW, int PH, int part, int fzoff = 0, int czoff = 0,
+                                                                int pzbeg = 0, int zmin = 1, int zmax = 0x7fffffff) {
     const Geo<XSplit, real> gf(fx, fy), gc(cx, cy);
     const int M = (fx + 1) >> 1;
-    const int pz = blockIdx.z;
+    const int pz = pzbeg + blockIdx.z;
     int i, py;
     if (part == 0) {
         i = blockIdx.x * 64 + threadIdx.x;
@@ -1286,7 +1296,7 @@ __global__ void __launch_bounds__(256) correct_pset3d_xs_kernel(real* __restrict
         if (py % PH == 0) return;
     }
     if (i >= M - 1 || py >= cy - 1) return;
-    interp_cell_xs<real, true, 1>(fine, gf, 0, coarse, gc, 0, i, py, pz);
+    interp_cell_xs<real, true, 1>(fine, gf, fzoff, coarse, gc, czoff, i, py, pz, zmin, zmax);
 }
 
 template <class real, class L>
@@ -2531,6 +2541,60 @@ int interpolate_correct3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff,
     return MGX_OK;
 }
 
+// ---- the coarse-grid correction read on the fly by the first red pass of the post-smoothing (relax3d_xs_pipe_kernel, VAR = 2)
+// does a level (rows of sx points, sy rows, `nplanes` planes to update) take it?
+static bool corr_fused_takes(const mgx_ctx* ctx, int sx, int sy, int sz_global, int nplanes) {
+    const bool small = sx <= SMALL_MAX && sy <= SMALL_MAX && sz_global <= SMALL_MAX && ctx->relax_small;
+    return ctx->corr_fuse && !small && ctx->relax_lds < 0 && (sx + 1) / 2 - 1 >= 128 && sy - 2 >= 64 && nplanes >= 8;
+}
+
+// the set P (tile-edge cells of that pass) corrected in place: the coarse cells covering the GLOBAL fine planes [zmin, zmax),
+// which are the only ones written.  v / coarse_v are local arrays starting at the global planes fzoff / czoff; every coarse
+// plane a written fine plane interpolates from must exist locally.
+template <class real>
+static void corr_pset_launch(mgx_ctx* ctx, real* v, int sx, int sy, int fzoff, const real* coarse_v, const int cn[3], int czoff, int zmin,
+                             int zmax) {
+    constexpr int PW = 128, PH = 8;  // the tile of relax3d_xs_pipe_kernel<real, 2, 8, 2>: 128 pairs x 16 rows
+    const int M = (sx + 1) / 2;
+    const int pzbeg = zmin / 2, pzend = (zmax - 1) / 2 + 1;
+    if (pzend <= pzbeg) return;
+    const int nk = (cn[1] - 2) / PH + 1;
+    hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ceil_div(M - 1, 64), ceil_div(nk, 4), pzend - pzbeg), blk(), 0, ctx->compute, v,
+                       sx, sy, coarse_v, cn[0], cn[1], PW, PH, 0, fzoff, czoff, pzbeg, zmin, zmax);
+    const int ncol = 2 * ((M - 1) / PW);
+    if (ncol > 0)
+        hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ncol, ceil_div(cn[1] - 1, 256), pzend - pzbeg), blk(), 0, ctx->compute, v, sx,
+                           sy, coarse_v, cn[0], cn[1], PW, PH, 1, fzoff, czoff, pzbeg, zmin, zmax);
+}
+
+// the red pass through the correction over the LOCAL planes [zb, ze) of v: `coarse_sh` = the coarse array shifted so that
+// local fine plane z interpolates from its planes z >> 1 (+ 1), szl = global plane count - global index of local plane 0,
+// ckmax = last plane of coarse_sh that exists; colour = 0 + parity of the slab's global offset
+template <class real>
+static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zb, int ze, real hx2, real hy2, real hz2, int colour,
+                            const real* coarse_sh, int cx, int cy, int szl, int ckmax) {
+    const int M = (sx + 1) / 2;
+    int zchunk = ctx->relax_zchunk;
+    if (zchunk <= 0) {  // one resident round of 16-wave workgroups as in relax3d_xs_pass_lds
+        const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, 16);
+        const int target = ctx->num_cus * (sizeof(real) == 4 ? 8 : 1);
+        const int nchunks = max(1, (target + tiles / 2) / tiles);
+        zchunk = max(8, ceil_div(ze - zb, nchunks));
+    }
+    const int gx = ceil_div(M - 1, 128), gy = ceil_div(sy - 2, 16), gz = ceil_div(ze - zb, zchunk);
+    const dim3 grid((unsigned)gx * gy * gz), block(64, 16, 1);
+    const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
+    const bool fnt = (size_t)sx * sy * (size_t)(ze - zb) * sizeof(real) > ((size_t)256 << 20);
+    snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,2,8,2,%s,2>", sizeof(real) == 8 ? "double" : "float",
+             fnt ? "true" : "false");
+    if (fnt)
+        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 8, 2, true, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
+                           hx2, hy2, hz2, colour, zchunk, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax);
+    else
+        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 8, 2, false, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
+                           hx2, hy2, hz2, colour, zchunk, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax);
+}
+
 // v += Interpolate(coarse_v) on the interior, then `ncycles` >= 1 red-black sweeps (N3/MultiGrid3D.cpp:638-645), x-split
 // layout.  On levels wide enough for the pipelined smoother most of the correction never goes through memory: the set P
 // (the cells on the edges of the smoother's workgroup tiles, about 1/8 of the black points) is corrected in place, the
@@ -2548,43 +2612,55 @@ int interpolate_correct_relax3d_xs(mgx_ctx* ctx, real* v, const real* f, const i
     if (st) return st;
     MGX_REQUIRE(ncycles >= 1, MGX_ERR_INVALID, "interpolate_correct_relax3d: ncycles = %d < 1 (use interpolate_correct)", ncycles);
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // :498-500
-    const int sx = n[0], sy = n[1], sz = n[2], M = (sx + 1) / 2, zb = 1, ze = sz - 1;
-    const bool small = sx <= SMALL_MAX && sy <= SMALL_MAX && sz <= SMALL_MAX && ctx->relax_small;
-    const bool fused = ctx->corr_fuse && !small && ctx->relax_lds < 0 && M - 1 >= 128 && sy - 2 >= 64 && ze - zb >= 8;
-    if (!fused) {
+    const int sx = n[0], sy = n[1], sz = n[2], zb = 1, ze = sz - 1;
+    if (!corr_fused_takes(ctx, sx, sy, sz, ze - zb)) {
         st = interpolate_correct3d_slab<real>(ctx, v, n, 0, coarse_v, cn, 0, 0, cn[2] - 1, 1);
         if (st) return st;
         return relax3d<real, XSplit>(ctx, v, f, n, h, ncycles);
     }
-    constexpr int PW = 128, PH = 8;  // the tile of relax3d_xs_pipe_kernel<real, 2, 8, 2>: 128 pairs x 16 rows
-    const int nk = (cn[1] - 2) / PH + 1;
-    hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ceil_div(M - 1, 64), ceil_div(nk, 4), cn[2] - 1), blk(), 0, ctx->compute, v,
-                       sx, sy, coarse_v, cn[0], cn[1], PW, PH, 0);
-    const int ncol = 2 * ((M - 1) / PW);
-    if (ncol > 0)
-        hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ncol, ceil_div(cn[1] - 1, 256), cn[2] - 1), blk(), 0, ctx->compute, v, sx,
-                           sy, coarse_v, cn[0], cn[1], PW, PH, 1);
-    // the first red pass through the correction: one resident round of 16-wave workgroups as in relax3d_xs_pass_lds
-    int zchunk = ctx->relax_zchunk;
-    if (zchunk <= 0) {
-        const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, 16);
-        const int target = ctx->num_cus * (sizeof(real) == 4 ? 8 : 1);
-        const int nchunks = max(1, (target + tiles / 2) / tiles);
-        zchunk = max(8, ceil_div(ze - zb, nchunks));
-    }
-    const int gx = ceil_div(M - 1, 128), gy = ceil_div(sy - 2, 16), gz = ceil_div(ze - zb, zchunk);
-    const dim3 grid((unsigned)gx * gy * gz), block(64, 16, 1);
-    const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
-    const bool fnt = (size_t)sx * sy * (size_t)(ze - zb) * sizeof(real) > ((size_t)256 << 20);
-    snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,2,8,2,%s,2>", sizeof(real) == 8 ? "double" : "float",
-             fnt ? "true" : "false");
-    if (fnt)
-        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 8, 2, true, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
-                           hx2, hy2, hz2, 0, zchunk, gx, gy, xcd, coarse_v, cn[0], cn[1], sz);
-    else
-        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 8, 2, false, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
-                           hx2, hy2, hz2, 0, zchunk, gx, gy, xcd, coarse_v, cn[0], cn[1], sz);
+    corr_pset_launch<real>(ctx, v, sx, sy, 0, coarse_v, cn, 0, 1, sz - 1);
+    corr_red_launch<real>(ctx, v, f, sx, sy, zb, ze, hx2, hy2, hz2, 0, coarse_v, cn[0], cn[1], sz, (sz - 1) >> 1);
     for (int s = 1; s < 2 * ncycles; s++) relax3d_xs_pass<real>(ctx, v, f, sx, sy, zb, ze, hx2, hy2, hz2, s & 1);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+// z-slab forms of the two pieces (multi-GPU post-smoothing, csrc/host/mg_dist3d.inc).  n / cn: GLOBAL sizes; v / f start at
+// global plane fzoff (even), coarse_v at czoff <= fzoff / 2 and holds cplanes planes.
+template <class real>
+int correct_pset3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff, const real* coarse_v, const int cn[3], int czoff, int zmin,
+                        int zmax) {
+    MGX_REQUIRE(ctx && v && coarse_v, MGX_ERR_INVALID, "correct_pset_slab: NULL argument");
+    MGX_USE(ctx);
+    int st = check_n3(n, "correct_pset_slab");
+    if (st) return st;
+    st = check_coarse3(n, cn, "correct_pset_slab");
+    if (st) return st;
+    MGX_REQUIRE(fzoff >= 0 && czoff >= 0 && zmin >= 1 && zmin >= fzoff && zmax <= n[2] - 1 && zmin / 2 >= czoff, MGX_ERR_INVALID,
+                "correct_pset_slab: bad plane window");
+    corr_pset_launch<real>(ctx, v, n[0], n[1], fzoff, coarse_v, cn, czoff, zmin, zmax);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+template <class real>
+int relax3d_corr_colour_slab(mgx_ctx* ctx, real* v, const real* f, const int n[3], int fzoff, const real h[3], const real* coarse_v,
+                             const int cn[3], int czoff, int cplanes, int zbeg, int zend) {
+    MGX_REQUIRE(ctx && v && f && h && coarse_v, MGX_ERR_INVALID, "relax_corr_colour_slab: NULL argument");
+    MGX_USE(ctx);
+    int st = check_n3(n, "relax_corr_colour_slab");
+    if (st) return st;
+    st = check_coarse3(n, cn, "relax_corr_colour_slab");
+    if (st) return st;
+    MGX_REQUIRE(fzoff >= 0 && (fzoff & 1) == 0 && czoff >= 0 && fzoff / 2 >= czoff && cplanes >= 1 && zbeg >= 1 && zend >= zbeg,
+                MGX_ERR_INVALID, "relax_corr_colour_slab: bad plane ranges (the slab must start on an even global plane)");
+    if (zend == zbeg) return MGX_OK;
+    const int ckmax = czoff + cplanes - 1 - fzoff / 2;
+    MGX_REQUIRE(ckmax >= (zend >> 1), MGX_ERR_INVALID, "relax_corr_colour_slab: the coarse slab does not reach the plane above the fine range");
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    const Geo<XSplit, real> gc(cn[0], cn[1]);
+    corr_red_launch<real>(ctx, v, f, n[0], n[1], zbeg, zend, hx2, hy2, hz2, 0, coarse_v + gc.PL * (size_t)(fzoff / 2 - czoff), cn[0], cn[1],
+                          n[2] - fzoff, ckmax);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -2823,6 +2899,19 @@ template int relax3d_xs_colour_passes<double>(mgx_ctx*, double*, const double*, 
                                                 const real h[3], const real* coarse_v, const int cn[3],          \
                                                 int ncycles) {                                                   \
         return mgx::interpolate_correct_relax3d_xs<real>(ctx, v, f, n, h, coarse_v, cn, ncycles);                \
+    }                                                                                                            \
+    int mgx3dxs_corr_fused_takes_##SFX(const mgx_ctx* ctx, const int n[3], int nplanes) {                        \
+        return ctx && n && mgx::corr_fused_takes(ctx, n[0], n[1], n[2], nplanes);                                \
+    }                                                                                                            \
+    int mgx3dxs_correct_pset_slab_##SFX(mgx_ctx* ctx, real* v, const int n[3], int fzoff, const real* coarse_v,  \
+                                        const int cn[3], int czoff, int zmin, int zmax) {                        \
+        return mgx::correct_pset3d_slab<real>(ctx, v, n, fzoff, coarse_v, cn, czoff, zmin, zmax);                \
+    }                                                                                                            \
+    int mgx3dxs_relax_corr_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], int fzoff,    \
+                                             const real h[3], const real* coarse_v, const int cn[3], int czoff,  \
+                                             int cplanes, int zbeg, int zend) {                                  \
+        return mgx::relax3d_corr_colour_slab<real>(ctx, v, f, n, fzoff, h, coarse_v, cn, czoff, cplanes, zbeg,   \
+                                                   zend);                                                        \
     }                                                                                                            \
     int mgx3dxs_interpolate_correct_colour_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,    \
                                                  const int cn[3], int colour) {                                  \

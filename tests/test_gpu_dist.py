@@ -127,6 +127,25 @@ def test_dist_vcycle_wide_rows_pipelined_smoother_on_slabs(nranks, dtype):
     assert bits_equal(got, want)
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("nranks,inline_bytes,v2", [(1, 0, 2), (2, 0, 1), (2, None, 3), (4, 0, 2), (8, None, 2)])
+def test_dist_correction_read_on_the_fly_on_slabs(nranks, inline_bytes, v2):
+    """levels with >= 257-point rows: the post-smoothing's first red pass reads v + Interpolate(coarse) on the fly on slabs
+    too (set P corrected in place incl. the ghost planes, no stored correction, no exchange of corrected planes); edge
+    planes, interior and ghost planes must all see the same corrections.  Two cycles, both exchange modes, the coarse
+    level distributed (2 ranks) or replicated (4, 8 ranks)."""
+    n3 = [257, 129, 129]
+    rng = np.random.default_rng(100 + nranks)
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    v0 = rng.uniform(-1, 1, O.shape(n3))
+    f0 = rng.uniform(-1, 1, O.shape(n3))
+    names = {}
+    got, info = run_ranks(nranks, n3, rg, np.float64, 2, v2, 2, 16, v0=v0, f0=f0, inline_bytes=inline_bytes,
+                          extra=lambda mg: names.setdefault(mg.rank, mg.ctx.last_relax_kernel()))
+    want = O.cycle3d(n3, rg, mode=0, v1=2, v2=v2, reps=2, v=v0, f=f0, dtype=np.float64)
+    assert bits_equal(got, want)
+
+
 @pytest.mark.timeout(200)
 @pytest.mark.parametrize("nranks", [2, 4])
 @pytest.mark.parametrize("inline_bytes", [None, 600_000, 100_000])
