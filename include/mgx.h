@@ -376,6 +376,10 @@ MGX_DECLARE_OPS(f64, double)
 #define MGX_UNIQUE_ID_BYTES 128
 int mgx_comm_unique_id(void* host_id_bytes);
 int mgx_comm_init(mgx_ctx* ctx, const void* host_id_bytes, int rank, int nranks);
+/* rehearsal of ONE rank of a larger job on a single GPU (timing only, results are meaningless): a one-rank RCCL
+ * communicator whose context reports (virtual_rank, virtual_nranks); every message keeps its size and its place in the
+ * schedule but travels from this rank to itself */
+int mgx_comm_init_rehearsal(mgx_ctx* ctx, const void* host_id_bytes, int virtual_rank, int virtual_nranks);
 int mgx_comm_destroy(mgx_ctx* ctx);
 int mgx_comm_rank(const mgx_ctx* ctx, int* rank, int* nranks);
 /* the number of ranks the communicator itself reports (ncclCommCount) and the RCCL version in use (ncclGetVersion) */

@@ -289,6 +289,28 @@ int mgx_comm_init(mgx_ctx* ctx, const void* host_id_bytes, int rank, int nranks)
     return MGX_OK;
 }
 
+// REHEARSAL of one rank of a larger job on a single GPU: a one-rank RCCL communicator, but the context reports
+// (virtual_rank, virtual_nranks), so that the slab plan, the overlap schedule, the stream / event pattern and the sizes of
+// every message are those of that rank; every send and receive goes to THIS rank (RCCL self send / recv, as
+// mgx_comm_selftest does), an all-gather receives its own share nranks times.  The planes received are wrong, so results
+// are meaningless: for timing one rank's share of a multi-GPU cycle where only one GPU is available (tools/rehearse_rank.py).
+int mgx_comm_init_rehearsal(mgx_ctx* ctx, const void* host_id_bytes, int virtual_rank, int virtual_nranks) {
+    MGX_REQUIRE(ctx && host_id_bytes, MGX_ERR_INVALID, "NULL argument");
+    MGX_REQUIRE(virtual_nranks >= 2 && virtual_rank >= 0 && virtual_rank < virtual_nranks, MGX_ERR_INVALID, "bad rank %d / %d", virtual_rank,
+                virtual_nranks);
+    MGX_REQUIRE(!ctx->rccl_comm && !ctx->local_group, MGX_ERR_INVALID, "communicator already initialised");
+    MGX_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, host_id_bytes, sizeof id);
+    ncclComm_t comm;
+    MGX_NCCL(ncclCommInitRank(&comm, 1, id, 0));
+    ctx->rccl_comm = (void*)comm;
+    ctx->rank = virtual_rank;
+    ctx->nranks = virtual_nranks;
+    ctx->comm_rehearse = 1;
+    return MGX_OK;
+}
+
 int mgx_local_group_create(int nranks, mgx_local_group** out) {
     MGX_REQUIRE(out && nranks >= 1 && nranks <= 64, MGX_ERR_INVALID, "bad arguments (1 <= nranks <= 64)");
     mgx_local_group* g = new mgx_local_group();
@@ -349,6 +371,7 @@ int mgx_comm_destroy(mgx_ctx* ctx) {
     }
     ctx->local_group = nullptr;
     ctx->comm_inline = 0;  // a communicator initialised later starts in overlapped mode
+    ctx->comm_rehearse = 0;
     ctx->rank = 0;
     ctx->nranks = 1;
     return MGX_OK;
@@ -398,14 +421,52 @@ int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_to_lower, size_t count
     if (st) return st;
     ncclComm_t comm = (ncclComm_t)ctx->rccl_comm;
     const ncclDataType_t dt = dtype_of(elem_bytes);
+    if (ctx->comm_rehearse) {
+        // both neighbours are this rank itself: sends and receives pair up in the order they are posted, and a message whose
+        // partner lives on another rank in the real job (the bottom / top rank of the chain) gets a scratch buffer as partner
+        const void* sp[2];
+        void* rp[2];
+        size_t sc[2], rc[2];
+        int ns = 0, nr = 0;
+        if (has_lo && count_to_lower) { sp[ns] = send_to_lower; sc[ns++] = count_to_lower; }
+        if (has_up && count_to_upper) { sp[ns] = send_to_upper; sc[ns++] = count_to_upper; }
+        if (has_lo && count_from_lower) { rp[nr] = recv_from_lower; rc[nr++] = count_from_lower; }
+        if (has_up && count_from_upper) { rp[nr] = recv_from_upper; rc[nr++] = count_from_upper; }
+        const int np = ns > nr ? ns : nr;
+        size_t need = 0;
+        for (int i = 0; i < np; i++) need += (i < ns ? sc[i] : rc[i]) * (size_t)elem_bytes;
+        if (ns != nr && ctx->rehearse_bytes < need) {
+            MGX_HIP(hipStreamSynchronize(ctx->compute));
+            MGX_HIP(hipStreamSynchronize(ctx->comm));
+            if (ctx->rehearse_buf) MGX_HIP(hipFree(ctx->rehearse_buf));
+            ctx->rehearse_buf = nullptr;
+            MGX_HIP(hipMalloc(&ctx->rehearse_buf, need));
+            MGX_HIP(hipMemset(ctx->rehearse_buf, 0, need));
+            ctx->rehearse_bytes = need;
+        }
+        char* scratch = (char*)ctx->rehearse_buf;
+        MGX_NCCL(ncclGroupStart());
+        for (int i = 0; i < np; i++) {
+            const size_t cnt = i < ns ? sc[i] : rc[i];
+            const void* src = i < ns ? sp[i] : (const void*)scratch;
+            void* dst = i < nr ? rp[i] : (void*)scratch;
+            MGX_REQUIRE(i >= ns || i >= nr || sc[i] == rc[i], MGX_ERR_INVALID, "rehearsal: a send of %zu meets a receive of %zu elements", sc[i], rc[i]);
+            MGX_NCCL(ncclSend(src, cnt, dt, 0, comm, cstream(ctx)));
+            MGX_NCCL(ncclRecv(dst, cnt, dt, 0, comm, cstream(ctx)));
+            if (i >= ns || i >= nr) scratch += cnt * (size_t)elem_bytes;
+        }
+        MGX_NCCL(ncclGroupEnd());
+        return MGX_OK;
+    }
+    const int lo = ctx->rank - 1, up = ctx->rank + 1;
     MGX_NCCL(ncclGroupStart());
     if (has_lo) {
-        if (count_to_lower) MGX_NCCL(ncclSend(send_to_lower, count_to_lower, dt, ctx->rank - 1, comm, cstream(ctx)));
-        if (count_from_lower) MGX_NCCL(ncclRecv(recv_from_lower, count_from_lower, dt, ctx->rank - 1, comm, cstream(ctx)));
+        if (count_to_lower) MGX_NCCL(ncclSend(send_to_lower, count_to_lower, dt, lo, comm, cstream(ctx)));
+        if (count_from_lower) MGX_NCCL(ncclRecv(recv_from_lower, count_from_lower, dt, lo, comm, cstream(ctx)));
     }
     if (has_up) {
-        if (count_to_upper) MGX_NCCL(ncclSend(send_to_upper, count_to_upper, dt, ctx->rank + 1, comm, cstream(ctx)));
-        if (count_from_upper) MGX_NCCL(ncclRecv(recv_from_upper, count_from_upper, dt, ctx->rank + 1, comm, cstream(ctx)));
+        if (count_to_upper) MGX_NCCL(ncclSend(send_to_upper, count_to_upper, dt, up, comm, cstream(ctx)));
+        if (count_from_upper) MGX_NCCL(ncclRecv(recv_from_upper, count_from_upper, dt, up, comm, cstream(ctx)));
     }
     MGX_NCCL(ncclGroupEnd());
     return MGX_OK;
@@ -453,6 +514,16 @@ int mgx_comm_allgather(mgx_ctx* ctx, const void* send, void* recv, size_t count,
     MGX_REQUIRE(ctx->rccl_comm, MGX_ERR_RCCL, "communicator not initialised");
     int st = order_after_compute(ctx);
     if (st) return st;
+    if (ctx->comm_rehearse) {  // every share arrives from this rank itself
+        ncclComm_t comm = (ncclComm_t)ctx->rccl_comm;
+        MGX_NCCL(ncclGroupStart());
+        for (int r = 0; r < ctx->nranks; r++) {
+            MGX_NCCL(ncclSend(send, count, dtype_of(elem_bytes), 0, comm, cstream(ctx)));
+            MGX_NCCL(ncclRecv((char*)recv + (size_t)r * count * elem_bytes, count, dtype_of(elem_bytes), 0, comm, cstream(ctx)));
+        }
+        MGX_NCCL(ncclGroupEnd());
+        return MGX_OK;
+    }
     MGX_NCCL(ncclAllGather(send, recv, count, dtype_of(elem_bytes), (ncclComm_t)ctx->rccl_comm, cstream(ctx)));
     return MGX_OK;
 }

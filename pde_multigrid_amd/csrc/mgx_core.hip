@@ -118,6 +118,7 @@ int mgx_ctx_destroy(mgx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->compute);
     (void)hipStreamSynchronize(ctx->comm);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->rehearse_buf) (void)hipFree(ctx->rehearse_buf);
     if (ctx->sweep_dev) (void)hipFree(ctx->sweep_dev);
     if (ctx->sweep_abort) (void)hipHostFree(ctx->sweep_abort);
     (void)hipEventDestroy(ctx->ev_compute);

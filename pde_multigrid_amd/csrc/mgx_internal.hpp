@@ -48,6 +48,9 @@ struct mgx_ctx {
     void* rccl_comm = nullptr;  // ncclComm_t
     void* local_group = nullptr;  // mgx_local_group* (in-process test transport)
     int rank = 0, nranks = 1;
+    int comm_rehearse = 0;  // mgx_comm_init_rehearsal: rank / nranks are pretended, every peer is this rank itself (timing only)
+    void* rehearse_buf = nullptr;  // its scratch: the partner buffer of a send / receive that has none on this rank
+    size_t rehearse_bytes = 0;
     int num_cus = 256;
     char last_relax_kernel[96] = "";  // name of the smoother kernel of the most recent colour pass (bench.py: roofline.kernel)
 };

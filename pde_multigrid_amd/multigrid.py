@@ -123,6 +123,11 @@ class Context:
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         check(lib.mgx_comm_init(self._h, buf, int(rank), int(nranks)))
 
+    def comm_init_rehearsal(self, unique_id, virtual_rank, virtual_nranks):
+        """one rank of a larger job rehearsed on this GPU alone (mgx_comm_init_rehearsal): timing only"""
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        check(lib.mgx_comm_init_rehearsal(self._h, buf, int(virtual_rank), int(virtual_nranks)))
+
     def comm_info(self):
         """(ranks the communicator reports, RCCL version code)"""
         n, v = C.c_int(0), C.c_int(0)
