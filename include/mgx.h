@@ -219,6 +219,25 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx3dxs_relax_pp_##SFX(mgx_ctx* ctx, real* v, real* w, const real* f, const int n[3],           \
                                const real h[3], int ncycles, int w_rim_valid);                          \
     int mgx3dxs_relax_pp_takes_##SFX(const mgx_ctx* ctx, const int n[3], int ncycles);                  \
+    /* On cache-resident levels (33 ... 129 points per row) relax_pp also runs one launch per sweep      */ \
+    /* (tile + halo in LDS, the neighbours' red values recomputed; "relax3d.fused_mid" = 0 turns it off). */ \
+    /* relax_from_zero_pp / interpolate_correct_relax_pp: mgx3dxs_relax_from_zero /                      */ \
+    /* mgx3dxs_interpolate_correct_relax with the same partner array for their sweeps; the first sweep of */ \
+    /* relax_from_zero_pp does not read v on those levels (even ncycles, rim_is_zero).  Same bits.        */ \
+    int mgx3dxs_relax_from_zero_pp_##SFX(mgx_ctx* ctx, real* v, real* w, const real* f, const int n[3], \
+                                         const real h[3], int ncycles, int rim_is_zero, int w_rim_valid); \
+    /* _takes: 1 when that call runs its sweeps on the partner array (and has brought w's boundary up to */ \
+    /* date), 0 when it is plain mgx3dxs_relax_from_zero                                                 */ \
+    /* sweep_once: ONE red+black sweep vin -> vout by the level's one-launch kernel (MGX_ERR_SIZE if it  */ \
+    /* has none): interior points of vout are written, nothing else; zero != 0: vin counts as zeros and   */ \
+    /* is not read (cache-resident levels).  The unit the _pp drivers are made of.                        */ \
+    int mgx3dxs_sweep_once_##SFX(mgx_ctx* ctx, const real* vin, real* vout, const real* f,              \
+                                 const int n[3], const real h[3], int zero);                            \
+    int mgx3dxs_relax_from_zero_pp_takes_##SFX(const mgx_ctx* ctx, const int n[3], int ncycles,         \
+                                               int rim_is_zero);                                        \
+    int mgx3dxs_interpolate_correct_relax_pp_##SFX(mgx_ctx* ctx, real* v, real* w, const real* f,       \
+                                                   const int n[3], const real h[3], const real* coarse_v, \
+                                                   const int cn[3], int ncycles, int w_rim_valid);      \
     int mgx3dxs_residual_##SFX(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[3],     \
                                const real h[3], int mode);                                              \
     int mgx3dxs_restrict_##SFX(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse,           \

@@ -2602,8 +2602,12 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
 // pass that follows recomputes all black interior points from red.  Elsewhere: the black points are corrected in place,
 // then the sweeps.  Both give the bits of interpolate_correct + relax.
 template <class real>
+int relax3d_xs_pp(mgx_ctx* ctx, real* v, real* w, const real* f, const int n[3], const real h[3], int ncycles, int w_rim_valid);  // mgx_sweep3d.hip
+
+// w != nullptr: a second array of the level's size as ping-pong partner for the sweeps (mgx3dxs_relax_pp)
+template <class real>
 int interpolate_correct_relax3d_xs(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], const real* coarse_v,
-                                   const int cn[3], int ncycles) {
+                                   const int cn[3], int ncycles, real* w = nullptr, int w_rim_valid = 0) {
     MGX_REQUIRE(ctx && v && f && h && coarse_v, MGX_ERR_INVALID, "interpolate_correct_relax3d: NULL argument");
     MGX_USE(ctx);
     int st = check_n3(n, "interpolate_correct_relax3d");
@@ -2616,6 +2620,7 @@ int interpolate_correct_relax3d_xs(mgx_ctx* ctx, real* v, const real* f, const i
     if (!corr_fused_takes(ctx, sx, sy, sz, ze - zb)) {
         st = interpolate_correct3d_slab<real>(ctx, v, n, 0, coarse_v, cn, 0, 0, cn[2] - 1, 1);
         if (st) return st;
+        if (w) return relax3d_xs_pp<real>(ctx, v, w, f, n, h, ncycles, w_rim_valid);
         return relax3d<real, XSplit>(ctx, v, f, n, h, ncycles);
     }
     corr_pset_launch<real>(ctx, v, sx, sy, 0, coarse_v, cn, 0, 1, sz - 1);
@@ -2789,6 +2794,12 @@ int relax3d_xs_colour_passes(mgx_ctx* ctx, real* v, const real* f, const int n[3
 }
 template int relax3d_xs_colour_passes<float>(mgx_ctx*, float*, const float*, const int[3], const float[3], int);
 template int relax3d_xs_colour_passes<double>(mgx_ctx*, double*, const double*, const int[3], const double[3], int);
+template <class real>
+int relax3d_xs_from_zero(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles, int rim_is_zero) {
+    return relax3d_from_zero<real, XSplit>(ctx, v, f, n, h, ncycles, rim_is_zero);
+}
+template int relax3d_xs_from_zero<float>(mgx_ctx*, float*, const float*, const int[3], const float[3], int, int);
+template int relax3d_xs_from_zero<double>(mgx_ctx*, double*, const double*, const int[3], const double[3], int, int);
 
 }  // namespace mgx
 
@@ -2913,6 +2924,12 @@ template int relax3d_xs_colour_passes<double>(mgx_ctx*, double*, const double*, 
         return mgx::relax3d_corr_colour_slab<real>(ctx, v, f, n, fzoff, h, coarse_v, cn, czoff, cplanes, zbeg,   \
                                                    zend);                                                        \
     }                                                                                                            \
+    int mgx3dxs_interpolate_correct_relax_pp_##SFX(mgx_ctx* ctx, real* v, real* w, const real* f, const int n[3], \
+                                                   const real h[3], const real* coarse_v, const int cn[3],       \
+                                                   int ncycles, int w_rim_valid) {                               \
+        if (!w) return mgx::fail(MGX_ERR_INVALID, "interpolate_correct_relax_pp: w is NULL");                    \
+        return mgx::interpolate_correct_relax3d_xs<real>(ctx, v, f, n, h, coarse_v, cn, ncycles, w, w_rim_valid); \
+    }                                                                                                            \
     int mgx3dxs_interpolate_correct_colour_##SFX(mgx_ctx* ctx, real* v, const int n[3], const real* coarse_v,    \
                                                  const int cn[3], int colour) {                                  \
         return mgx::interpolate_correct3d_slab<real>(ctx, v, n, 0, coarse_v, cn, 0, 0, cn ? cn[2] - 1 : 0,       \
@@ -3005,6 +3022,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         ctx->cyc2_tail_points = value;
     } else if (!strcmp(name, "relax3d.fused")) {
         ctx->sweep_fused = value ? 1 : 0;  // levels of 513-point rows: one launch per red+black sweep (mgx_sweep3d.hip) or one per colour
+    } else if (!strcmp(name, "relax3d.fused_mid")) {
+        ctx->sweep_mid = value ? 1 : 0;  // cache-resident levels (33 ... 129 points per row): one launch per sweep (sweep3d_xs_mid_kernel)
     } else if (!strcmp(name, "relax3d.fused_dbg")) {
 #ifdef MGX_DIAGNOSTICS
         ctx->sweep_dbg = value;  // 1 = cycle stamps, + 2 * ablation bits: WRONG results

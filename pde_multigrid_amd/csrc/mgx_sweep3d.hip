@@ -417,6 +417,154 @@ __global__ void __launch_bounds__(64 * WX * WY)
     }
 }
 
+// ------------------------------------------------------------------ one launch per sweep on the cache-resident levels
+// Levels of 33 ... 129 points per row hold a few MB: a colour pass is a 3-5 us launch that moves almost nothing, and a
+// V(2,2) cycle spends ten such launches per level.  Here ONE launch does a whole red+black sweep, out of place: a workgroup
+// loads the old black values of its tile (all of x, TY rows, TZ planes) plus TWO rows / planes around it into LDS, computes
+// red on the tile plus ONE row / plane around it (the red values its black points need from its neighbours' tiles are
+// recomputed, from the same inputs with the same expression: same bits), then black on the tile.  LDS holds, per row, one
+// entry per x-pair: B = the old black value of the pair, Rd = its new red value.  In row (y, z) the red point of pair i is
+// x = 2 i + q, its x-neighbours are the pair's own black value and that of pair i + 1 (q = 1) or i - 1 (q = 0); its y / z
+// neighbours are the black values of the SAME pair index in the adjacent rows (the parity flips with y and z).  Pair M - 1
+// is the single boundary point x = sx - 1.  ZERO: the input counts as all zeros and is not read (the first sweep on a
+// coarse level, N3/MultiGrid3D.cpp:634 + :626).
+template <class real>
+__global__ void __launch_bounds__(1024) sweep3d_xs_mid_kernel(const real* __restrict__ vin, real* __restrict__ vout,
+                                                              const real* __restrict__ f, int sx, int sy, int sz, real hx2, real hy2,
+                                                              real hz2, int c0, int TY, int TZ, int gy, int zero) {
+    const bool ZERO = zero != 0;  // a run-time flag on purpose: see the note at step 1
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    const double rd = relax3d_rd<real>(hx2, hy2, hz2);
+    const Geo<XSplit, real> g(sx, sy);
+    const int H = g.H, M = (sx + 1) >> 1;
+    const int by = blockIdx.x % gy, bz = blockIdx.x / gy;
+    const int y0 = 1 + by * TY, y1 = min(y0 + TY, sy - 1), z0 = 1 + bz * TZ, z1 = min(z0 + TZ, sz - 1);
+    const int ya = max(y0 - 2, 0), yb = min(y1 + 2, sy), za = max(z0 - 2, 0), zb = min(z1 + 2, sz);  // old black
+    const int ra = max(y0 - 1, 0), rb = min(y1 + 1, sy), sa = max(z0 - 1, 0), sb = min(z1 + 1, sz);  // new red
+    const int BW = M, BP = M * (TY + 4), RW = M, RP = M * (TY + 2);  // LDS strides (pairs, rows, planes)
+    real* B = (real*)smem_;
+    real* Rd = B + (size_t)BP * (TZ + 4);
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const SmallDiv dM(M);
+    // Every phase works through its items in chunks of U per thread: first ALL global loads of a chunk are issued (old values,
+    // f), then the chunk is computed -- one memory round trip per chunk instead of one per item (items are independent).
+    constexpr int U = 6;
+    // 1. the old black values of the rows [ya, yb) x [za, zb) (ZERO: zeros, nothing is read).  ZERO is a run-time flag: as a
+    // template parameter the specialised kernel gave wrong values next to boundary faces whenever the previous launch had left
+    // non-zero data in LDS (hipcc 7.2; found by sweep_once against the oracle, not understood) -- the generic code path with
+    // two selects is bit-exact.
+    {
+        const int NY = yb - ya, n = (zb - za) * NY * M;
+        const SmallDiv dNY(NY);
+        for (int base = tid; base < n; base += nt * U) {
+            real tmp[U];
+            int li[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = base + u * nt;
+                li[u] = -1;
+                tmp[u] = 0;
+                if (t < n) {
+                    const int r = dM(t), i = t - r * M, zz = dNY(r), yy = r - zz * NY, y = ya + yy, z = za + zz;
+                    const int q = (c0 + 1 + y + z) & 1;
+                    li[u] = i + yy * BW + zz * BP;
+                    if (!ZERO && 2 * i + q < sx) tmp[u] = vin[g.row(y, z) + q * H + i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (li[u] >= 0) B[li[u]] = tmp[u];
+        }
+    }
+    __syncthreads();
+    // 2. red on the tile and one row / plane around it (boundary points keep their value)
+    {
+        const int NY = rb - ra, n = (sb - sa) * NY * M;
+        const SmallDiv dNY(NY);
+        for (int base = tid; base < n; base += nt * U) {
+            real fv[U];
+            int li[U], bi[U], kind[U];  // kind: -1 none, 0 no point (x = sx), 1 boundary (fv = its value), 2 interior halo, 3 interior own
+            size_t gidx[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = base + u * nt;
+                kind[u] = -1;
+                fv[u] = 0;
+                li[u] = bi[u] = 0;
+                gidx[u] = 0;
+                if (t < n) {
+                    const int r = dM(t), i = t - r * M, zz = dNY(r), yy = r - zz * NY, y = ra + yy, z = sa + zz;
+                    const int q = (c0 + y + z) & 1, x = 2 * i + q;
+                    li[u] = i + yy * RW + zz * RP;
+                    bi[u] = (i + (y - ya) * BW + (z - za) * BP) * 2 + q;
+                    kind[u] = 0;
+                    if (x < sx) {
+                        gidx[u] = g.row(y, z) + q * H + i;
+                        if (x == 0 || x == sx - 1 || y == 0 || y == sy - 1 || z == 0 || z == sz - 1) {
+                            kind[u] = 1;
+                            if (!ZERO) fv[u] = vin[gidx[u]];
+                        } else {
+                            kind[u] = (y >= y0 && y < y1 && z >= z0 && z < z1) ? 3 : 2;
+                            fv[u] = f[gidx[u]];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (kind[u] < 0) continue;
+                real val = (real)0;
+                if (!ZERO && kind[u] == 1) val = fv[u];
+                if (kind[u] >= 2) {
+                    {
+                        const int q = bi[u] & 1;
+                        const real* b = B + (bi[u] >> 1);  // the pair's own black value (x + 1 - 2 q)
+                        const real side = q ? b[1] : b[-1];
+                        val = relax3d_point_rd<real>(q ? b[0] : side, q ? side : b[0], b[-BW], b[BW], b[-BP], b[BP], fv[u], hx2, hy2, hz2, rd);
+                    }
+                    if (kind[u] == 3) vout[gidx[u]] = val;
+                }
+                Rd[li[u]] = val;
+            }
+        }
+    }
+    __syncthreads();
+    // 3. black on the tile
+    {
+        const int NY = y1 - y0, n = (z1 - z0) * NY * M;
+        const SmallDiv dNY(NY);
+        for (int base = tid; base < n; base += nt * U) {
+            real fv[U];
+            int pi[U];
+            size_t gidx[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = base + u * nt;
+                pi[u] = -1;
+                fv[u] = 0;
+                gidx[u] = 0;
+                if (t < n) {
+                    const int r = dM(t), i = t - r * M, zz = dNY(r), y = y0 + r - zz * NY, z = z0 + zz;
+                    const int q = (c0 + 1 + y + z) & 1, x = 2 * i + q;
+                    if (x >= 1 && x < sx - 1) {
+                        gidx[u] = g.row(y, z) + q * H + i;
+                        pi[u] = (i + (y - ra) * RW + (z - sa) * RP) * 2 + q;
+                        fv[u] = f[gidx[u]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (pi[u] < 0) continue;
+                const int q = pi[u] & 1;
+                const real* p = Rd + (pi[u] >> 1);  // the pair's own red value
+                const real side = q ? p[1] : p[-1];
+                vout[gidx[u]] = relax3d_point_rd<real>(q ? p[0] : side, q ? side : p[0], p[-RW], p[RW], p[-RP], p[RP], fv[u], hx2, hy2, hz2, rd);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ boundary faces of v -> w
 // The sweep kernel never writes boundary points; a ping-pong partner must carry v's boundary values before it becomes
 // the input of the next sweep (or the result).  One workgroup per (plane, part): the planes z = 0 and sz - 1 whole, of the
@@ -474,9 +622,30 @@ static int sweep_state(mgx_ctx* ctx, SweepSync* out) {
     return MGX_OK;
 }
 
+constexpr int SWEEP_MID = 1;  // shape code of sweep3d_xs_mid_kernel
+
+// tile (TY rows x TZ planes) of the mid-level kernel: at least ~128 workgroups where the level has them, LDS within 150 KB
+template <class real>
+static bool sweep3d_mid_tile(int sx, int sy, int sz, int* TY, int* TZ) {
+    // measured (tools/level_timing.py, 513^3 cycle, MI355X): 33^3 level 44 -> 37 us per visit, 65^3 equal, 129^3 78 -> 100 us (256
+    // workgroups of 1024 threads doing 2.6 x the arithmetic lose against two 5 us passes): rows of at most 65 points only
+    if (sx > 65 || sx < 33 || sy < 9 || sz < 9) return false;
+    int ty = 8, tz = 8;
+    auto wgs = [&]() { return ceil_div(sy - 2, ty) * ceil_div(sz - 2, tz); };
+    auto bytes = [&]() { return (size_t)((sx + 1) / 2) * ((ty + 4) * (tz + 4) + (ty + 2) * (tz + 2)) * sizeof(real); };
+    if (wgs() < 128 || bytes() > 150 * 1024) tz = 4;
+    if (wgs() < 128 && sy - 2 > 4) ty = 4;
+    if (bytes() > 150 * 1024) return false;
+    *TY = ty;
+    *TZ = tz;
+    return true;
+}
+
 // shape (WX, WY, R) of the fused sweep for a level, 0 if the level does not take it
 template <class real>
 static int sweep3d_shape(const mgx_ctx* ctx, int sx, int sy, int sz) {
+    int ty, tz;
+    if (ctx->sweep_mid && sweep3d_mid_tile<real>(sx, sy, sz, &ty, &tz)) return SWEEP_MID;
     if (!ctx->sweep_fused || ctx->nranks > 1 || ctx->local_group) return 0;  // thread-ranks share one GPU: co-residency is not given
     const int M = (sx + 1) / 2;
     if (M - 1 != 256) return 0;          // tiles span the x-extent: 513-point rows (4 waves of 64 pairs)
@@ -522,11 +691,31 @@ static int sweep3d_launch_shape(mgx_ctx* ctx, const real* vin, real* vout, const
     return MGX_OK;
 }
 
+template <class real>
+static int sweep3d_mid_launch(mgx_ctx* ctx, const real* vin, real* vout, const real* f, int sx, int sy, int sz, real hx2, real hy2, real hz2,
+                              bool zero) {
+    int TY = 8, TZ = 8;
+    MGX_REQUIRE(sweep3d_mid_tile<real>(sx, sy, sz, &TY, &TZ), MGX_ERR_SIZE, "sweep3d_mid: level %d x %d x %d does not take the kernel", sx, sy, sz);
+    const size_t lds = (size_t)((sx + 1) / 2) * ((TY + 4) * (TZ + 4) + (TY + 2) * (TZ + 2)) * sizeof(real);
+    const int gy = ceil_div(sy - 2, TY), gz = ceil_div(sz - 2, TZ);
+    const int threads = (size_t)TY * TZ * ((sx + 1) / 2) >= 2048 ? 1024 : 512;
+    if (lds > 64 * 1024) {
+        MGX_HIP(hipFuncSetAttribute((const void*)sweep3d_xs_mid_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "sweep3d_xs_mid_kernel<%s>%s", sizeof(real) == 8 ? "double" : "float",
+             zero ? " (from zero)" : "");
+    hipLaunchKernelGGL((sweep3d_xs_mid_kernel<real>), dim3(gy * gz), dim3(threads), lds, ctx->compute, vin, vout, f, sx, sy, sz, hx2, hy2, hz2,
+                       0, TY, TZ, gy, zero ? 1 : 0);
+    return MGX_OK;
+}
+
 // one red+black sweep vin -> vout (boundary entries of vout are not written)
 template <class real>
 static int sweep3d_launch(mgx_ctx* ctx, int shape, const real* vin, real* vout, const real* f, int sx, int sy, int sz, real hx2, real hy2,
-                          real hz2) {
+                          real hz2, bool zero = false) {
     const int lead = ctx->sweep_lead;
+    if (shape == SWEEP_MID) return sweep3d_mid_launch<real>(ctx, vin, vout, f, sx, sy, sz, hx2, hy2, hz2, zero);
+    MGX_REQUIRE(!zero, MGX_ERR_INVALID, "sweep3d: no from-zero form of shape %d", shape);
     switch (shape) {
         case 424:
             if (lead == 5) return sweep3d_launch_shape<real, 4, 2, 4, 5>(ctx, vin, vout, f, sx, sy, sz, hx2, hy2, hz2, 0);
@@ -569,9 +758,79 @@ int relax3d_xs_pp(mgx_ctx* ctx, real* v, real* w, const real* f, const int n[3],
     return MGX_OK;
 }
 
+template int relax3d_xs_pp<float>(mgx_ctx*, float*, float*, const float*, const int[3], const float[3], int, int);
+template int relax3d_xs_pp<double>(mgx_ctx*, double*, double*, const double*, const int[3], const double[3], int, int);
+
+template <class real>
+int relax3d_xs_from_zero(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles, int rim_is_zero);  // mgx_kernels3d.hip
+
+template <class real>
+static bool from_zero_pp_takes(const mgx_ctx* ctx, const int n[3], int ncycles, int rim_is_zero) {
+    return ncycles >= 2 && (ncycles & 1) == 0 && rim_is_zero && ctx->relax_zero_first && sweep3d_shape<real>(ctx, n[0], n[1], n[2]) == SWEEP_MID;
+}
+
+// relax_from_zero with a ping-pong partner: v := 0 (N3/MultiGrid3D.cpp:634), then `ncycles` sweeps (:626).  On the
+// cache-resident levels, with the boundary of v known to be zero and an even sweep count, the first sweep does not read v
+// at all (sweep3d_xs_mid_kernel with zero = 1) and every sweep is one launch; otherwise mgx3dxs_relax_from_zero.
+template <class real>
+int relax3d_xs_from_zero_pp(mgx_ctx* ctx, real* v, real* w, const real* f, const int n[3], const real h[3], int ncycles, int rim_is_zero,
+                            int w_rim_valid) {
+    MGX_REQUIRE(ctx && v && w && f && h && n, MGX_ERR_INVALID, "relax_from_zero_pp3d: NULL argument");
+    MGX_REQUIRE(v != w, MGX_ERR_INVALID, "relax_from_zero_pp3d: v and w must differ");
+    MGX_USE(ctx);
+    for (int d = 0; d < 3; d++) MGX_REQUIRE(valid_size(n[d]), MGX_ERR_SIZE, "relax_from_zero_pp3d: size[%d] = %d is not 2^k+1 >= 3", d, n[d]);
+    const int shape = from_zero_pp_takes<real>(ctx, n, ncycles, rim_is_zero) ? SWEEP_MID : 0;
+    if (shape != SWEEP_MID) return relax3d_xs_from_zero<real>(ctx, v, f, n, h, ncycles, rim_is_zero);
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    if (!w_rim_valid) {  // the boundary of v is zero: so must be w's
+        hipLaunchKernelGGL((copy_rim3d_xs_kernel<real>), dim3(n[2], 4), dim3(256), 0, ctx->compute, (const real*)v, w, n[0], n[1], n[2]);
+        MGX_LAUNCH_CHECK();
+    }
+    for (int k = 0; k < ncycles; k += 2) {
+        MGX_TRY_RET(sweep3d_launch<real>(ctx, shape, v, w, f, n[0], n[1], n[2], hx2, hy2, hz2, k == 0));
+        MGX_TRY_RET(sweep3d_launch<real>(ctx, shape, w, v, f, n[0], n[1], n[2], hx2, hy2, hz2));
+    }
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
 }  // namespace mgx
 
 extern "C" {
+int mgx3dxs_relax_from_zero_pp_f32(mgx_ctx* ctx, float* v, float* w, const float* f, const int n[3], const float h[3], int ncycles,
+                                   int rim_is_zero, int w_rim_valid) {
+    return mgx::relax3d_xs_from_zero_pp<float>(ctx, v, w, f, n, h, ncycles, rim_is_zero, w_rim_valid);
+}
+int mgx3dxs_relax_from_zero_pp_f64(mgx_ctx* ctx, double* v, double* w, const double* f, const int n[3], const double h[3], int ncycles,
+                                   int rim_is_zero, int w_rim_valid) {
+    return mgx::relax3d_xs_from_zero_pp<double>(ctx, v, w, f, n, h, ncycles, rim_is_zero, w_rim_valid);
+}
+// ONE out-of-place sweep vin -> vout (interior points of vout only) by the one-launch kernel of the level, if it has one
+// (MGX_ERR_SIZE otherwise); zero != 0: vin counts as all zeros and is not read (cache-resident levels only).  The unit the
+// ping-pong drivers above are made of; exposed for tests.
+#define MGX_SWEEP_ONCE(SFX, real)                                                                                              \
+    int mgx3dxs_sweep_once_##SFX(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const int n[3], const real h[3],    \
+                                 int zero) {                                                                                   \
+        MGX_REQUIRE(ctx && vin && vout && f && n && h && vin != vout, MGX_ERR_INVALID, "sweep_once: bad argument");            \
+        MGX_USE(ctx);                                                                                                          \
+        for (int d = 0; d < 3; d++) MGX_REQUIRE(mgx::valid_size(n[d]), MGX_ERR_SIZE, "sweep_once: size[%d] = %d", d, n[d]);    \
+        const int shape = mgx::sweep3d_shape<real>(ctx, n[0], n[1], n[2]);                                                     \
+        MGX_REQUIRE(shape != 0, MGX_ERR_SIZE, "sweep_once: this level has no one-launch sweep");                               \
+        MGX_TRY_RET(mgx::sweep3d_launch<real>(ctx, shape, vin, vout, f, n[0], n[1], n[2], h[0] * h[0], h[1] * h[1], h[2] * h[2], \
+                                              zero != 0));                                                                     \
+        MGX_LAUNCH_CHECK();                                                                                                    \
+        return MGX_OK;                                                                                                         \
+    }
+MGX_SWEEP_ONCE(f32, float)
+MGX_SWEEP_ONCE(f64, double)
+#undef MGX_SWEEP_ONCE
+
+int mgx3dxs_relax_from_zero_pp_takes_f32(const mgx_ctx* ctx, const int n[3], int ncycles, int rim_is_zero) {
+    return ctx && n && mgx::from_zero_pp_takes<float>(ctx, n, ncycles, rim_is_zero);
+}
+int mgx3dxs_relax_from_zero_pp_takes_f64(const mgx_ctx* ctx, const int n[3], int ncycles, int rim_is_zero) {
+    return ctx && n && mgx::from_zero_pp_takes<double>(ctx, n, ncycles, rim_is_zero);
+}
 int mgx3dxs_relax_pp_f32(mgx_ctx* ctx, float* v, float* w, const float* f, const int n[3], const float h[3], int ncycles, int w_rim_valid) {
     return mgx::relax3d_xs_pp<float>(ctx, v, w, f, n, h, ncycles, w_rim_valid);
 }

@@ -273,6 +273,32 @@ class _Ops3D(_Ops):
         return self._run(ctx, [v, w, f], lambda a, ww, b: fn(ctx._h, a, ww, b, _ip(n), h, C.c_int(ncycles), C.c_int(int(w_rim_valid))),
                          0, _shape(n), dtype)
 
+    def relax_from_zero_pp(self, ctx, v, f, n, rng, ncycles, rim_is_zero, w=None, w_rim_valid=False, dtype=None):
+        """x-split only: relax_from_zero with a ping-pong partner (mgx3dxs_relax_from_zero_pp)"""
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("relax_from_zero_pp", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        if w is None:
+            w = np.full(_shape(n), np.nan, dtype)
+        return self._run(ctx, [v, w, f], lambda a, ww, b: fn(ctx._h, a, ww, b, _ip(n), h, C.c_int(ncycles), C.c_int(int(rim_is_zero)),
+                                                            C.c_int(int(w_rim_valid))), 0, _shape(n), dtype)
+
+    def interpolate_correct_relax_pp(self, ctx, v, f, n, rng, coarse, ncycles, dtype=None):
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("interpolate_correct_relax_pp", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        cn = coarse_size(n)
+        w = np.full(_shape(n), np.nan, dtype)
+        return self._run(ctx, [v, w, f, coarse], lambda a, ww, b, c: fn(ctx._h, a, ww, b, _ip(n), h, c, _ip(cn), C.c_int(ncycles), C.c_int(0)),
+                         0, _shape(n), dtype)
+
+    def sweep_once(self, ctx, vin, vout, f, n, rng, zero=False, dtype=None):
+        """x-split only: one out-of-place sweep vin -> vout (interior of vout) by the level's one-launch kernel"""
+        dtype = dtype or vin.dtype
+        fn, ct = self._fn("sweep_once", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        return self._run(ctx, [vin, vout, f], lambda a, o, b: fn(ctx._h, a, o, b, _ip(n), h, C.c_int(int(zero))), 1, _shape(n), dtype)
+
     def relax_pp_takes(self, ctx, n, ncycles, dtype=np.float64):
         s, _ = _ct(dtype)
         return bool(getattr(lib, "mgx3dxs_relax_pp_takes_" + s)(ctx._h, _ip(n), C.c_int(ncycles)))

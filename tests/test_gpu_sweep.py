@@ -88,10 +88,82 @@ def test_sweep_off_switch_and_small_levels(ctx):
     finally:
         ctx.set_param("relax3d.fused", 1)
     assert bits_equal(got, O.relax3d(n3, RG, v, f, 2, dtype=np.float64))
-    n3 = (129, 65, 33)  # not a level of 513-point rows: colour passes
+    n3 = (129, 65, 33)  # neither a level of 513-point rows nor one of at most 65: colour passes
     assert not P.ops3dxs.relax_pp_takes(ctx, n3, 2)
     v, f = _data(n3, np.float64)
     assert bits_equal(P.ops3dxs.relax_pp(ctx, v, f, n3, RG, 2), O.relax3d(n3, RG, v, f, 2, dtype=np.float64))
+    n3 = (17, 17, 17)  # one-workgroup kernel
+    assert not P.ops3dxs.relax_pp_takes(ctx, n3, 2)
+
+
+# ------------------------------------------------------------------ cache-resident levels: one launch per sweep, halo recomputed
+MID = [(65, 65, 65), (33, 33, 33), (65, 33, 129), (65, 129, 9), (33, 9, 129), (33, 65, 17)]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n3", MID)
+def test_mid_sweep_matches_oracle(ctx, n3, dtype):
+    assert P.ops3dxs.relax_pp_takes(ctx, n3, 2, dtype)
+    v, f = _data(n3, dtype, seed=sum(n3))  # random boundary values too
+    for ncycles in (2, 3, 4):
+        got = P.ops3dxs.relax_pp(ctx, v, f, n3, RG, ncycles)
+        assert ctx.last_relax_kernel().startswith("sweep3d_xs_mid_kernel"), ctx.last_relax_kernel()
+        assert bits_equal(got, O.relax3d(n3, RG, v, f, ncycles, dtype=dtype)), ncycles
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n3", [(65, 65, 65), (65, 33, 129), (33, 33, 33)])
+def test_mid_relax_from_zero(ctx, n3, dtype):
+    """v counts as zeros: junk in the interior must not matter, the boundary is zero by contract; 2 sweeps: the first does not
+    read v; 3 sweeps and a non-zero boundary: the plain path"""
+    v, f = _data(n3, dtype, seed=1)
+    v[0], v[-1], v[:, 0], v[:, -1], v[:, :, 0], v[:, :, -1] = 0, 0, 0, 0, 0, 0
+    zero = np.zeros_like(v)
+    for ncycles in (2, 4, 3):
+        got = P.ops3dxs.relax_from_zero_pp(ctx, v, f, n3, RG, ncycles, True)
+        assert bits_equal(got, O.relax3d(n3, RG, zero, f, ncycles, dtype=dtype)), ncycles
+    v2, _ = _data(n3, dtype, seed=2)  # non-zero boundary: rim_is_zero = False -> everything is zeroed first
+    got = P.ops3dxs.relax_from_zero_pp(ctx, v2, f, n3, RG, 2, False)
+    assert bits_equal(got, O.relax3d(n3, RG, zero, f, 2, dtype=dtype))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n3", [(65, 65, 65), (65, 129, 33), (33, 33, 33), (33, 9, 65)])
+def test_mid_single_sweeps_out_of_place(ctx, n3, dtype):
+    """the unit the ping-pong drivers are made of, alone and repeatedly on one context (LDS and registers carry the previous
+    launch's values): vin -> vout, generic and from-zero form; vout's boundary (NaN here) is neither read nor written"""
+    v, f = _data(n3, dtype, seed=11)
+    zero = np.zeros_like(v)
+    nanw = np.full_like(v, np.nan)
+    inner = (slice(1, -1),) * 3
+    want, wantz = O.relax3d(n3, RG, v, f, 1, dtype=dtype), O.relax3d(n3, RG, zero, f, 1, dtype=dtype)
+    for _ in range(3):
+        got = P.ops3dxs.sweep_once(ctx, v, nanw, f, n3, RG)
+        assert bits_equal(got[inner], want[inner]) and np.isnan(got[0]).all() and np.isnan(got[:, :, -1]).all()
+        got = P.ops3dxs.sweep_once(ctx, v, nanw, f, n3, RG, zero=True)  # v (junk, non-zero boundary) must not matter
+        assert bits_equal(got[inner], wantz[inner])
+
+
+@pytest.mark.parametrize("n3", [(65, 65, 65), (65, 129, 33)])
+def test_mid_interpolate_correct_relax(ctx, n3):
+    v, f = _data(n3, np.float64, seed=4)
+    cn = P.coarse_size(n3)
+    c = np.random.default_rng(5).uniform(-1, 1, tuple(reversed(cn)))
+    want = O.relax3d(n3, RG, O.correct3d(n3, v, O.interpolate3d(n3, v, c, dtype=np.float64), dtype=np.float64), f, 2, dtype=np.float64)
+    assert bits_equal(P.ops3dxs.interpolate_correct_relax_pp(ctx, v, f, n3, RG, c, 2), want)
+
+
+def test_mid_off_switch(ctx):
+    n3 = (65, 65, 33)
+    v, f = _data(n3, np.float64)
+    ctx.set_param("relax3d.fused_mid", 0)
+    try:
+        assert not P.ops3dxs.relax_pp_takes(ctx, n3, 2)
+        got = P.ops3dxs.relax_pp(ctx, v, f, n3, RG, 2)
+        assert not ctx.last_relax_kernel().startswith("sweep3d")
+    finally:
+        ctx.set_param("relax3d.fused_mid", 1)
+    assert bits_equal(got, O.relax3d(n3, RG, v, f, 2, dtype=np.float64))
 
 
 def test_sweep_many_launches_epochs(ctx):
