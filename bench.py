@@ -395,8 +395,9 @@ def main():
     comm = None
     if slabbed:
         seen, ver = ctx.comm_info()
-        comm = {"ranks_seen": seen, "rccl_version": ver, "launcher": "torch.distributed.run environment" if "MGX_RDZV_KEY" not in os.environ
-                else "bench.py's own children", "control_plane": "pde_multigrid_amd/launch.py (TCP on 127.0.0.1)",
+        launcher = ("bench.py's own children" if "MGX_RDZV_KEY" in os.environ else
+                    "an external launcher's environment (RANK / WORLD_SIZE)" if "WORLD_SIZE" in os.environ else "this process alone")
+        comm = {"ranks_seen": seen, "rccl_version": ver, "launcher": launcher, "control_plane": "pde_multigrid_amd/launch.py (TCP on 127.0.0.1)",
                 "torch_imported": "torch" in sys.modules}
 
     if rank == 0:
