@@ -40,6 +40,7 @@ struct mgx_ctx {
     int sweep_fused = 0;   // 1: one launch per red+black sweep where the level takes it (mgx_sweep3d.hip); 0 = one per colour (default
                            // while the one-launch kernel measures slower: DESIGN.md section 5)
     int sweep_mid = 1;     // cache-resident levels (33 ... 129 points per row): one launch per red+black sweep (sweep3d_xs_mid_kernel)
+    int sweep_ilv = 0;     // that kernel with its memory instructions interleaved with the arithmetic instead of issued first
     int sweep_lead = 0;    // planes the red stage of that kernel runs ahead of the black stage (0 = default)
     int sweep_dbg = 0;     // diagnostic builds: 1 = cycle stamps, + 2 * ablation bits (sweep3d_xs_kernel)
     void* sweep_dev = nullptr;        // its device state: launch epoch, finished-workgroup counter, progress words

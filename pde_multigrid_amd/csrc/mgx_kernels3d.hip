@@ -3022,6 +3022,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         ctx->cyc2_tail_points = value;
     } else if (!strcmp(name, "relax3d.fused")) {
         ctx->sweep_fused = value ? 1 : 0;  // levels of 513-point rows: one launch per red+black sweep (mgx_sweep3d.hip) or one per colour
+    } else if (!strcmp(name, "relax3d.fused_ilv")) {
+        ctx->sweep_ilv = value ? 1 : 0;  // sweep3d_xs_kernel: memory instructions in groups between the rows of the arithmetic (1) or all first (0)
     } else if (!strcmp(name, "relax3d.fused_mid")) {
         ctx->sweep_mid = value ? 1 : 0;  // cache-resident levels (33 ... 129 points per row): one launch per sweep (sweep3d_xs_mid_kernel)
     } else if (!strcmp(name, "relax3d.fused_dbg")) {

@@ -59,7 +59,7 @@ constexpr unsigned SWEEP_SPIN_LIMIT = 1u << 21;  // polls (each ~1 us) before a 
 // DBG (diagnostic builds only): per-wave cycle stamps of the phases of a step go to `dbg`, `abl` switches parts off
 // (WRONG results): 1 no waits on progress words, 2 no write-through / sc1 accesses, 4 no black arithmetic, 8 no red
 // arithmetic, 16 no global stores.
-template <class real, int WX, int WY, int R, int D, bool FNT, int DBG = 0>
+template <class real, int WX, int WY, int R, int D, bool FNT, int DBG = 0, bool ILV = false>
 __global__ void __launch_bounds__(64 * WX * WY)
     sweep3d_xs_kernel(const real* __restrict__ vin, real* vout, const real* __restrict__ f, int sx, int sy, int sz, int zbeg,
                       int zend, real hx2, real hy2, real hz2, int c0, int zchunk, int gy, int xcd_mode, SweepSync sync,
@@ -204,153 +204,207 @@ __global__ void __launch_bounds__(64 * WX * WY)
         const bool blk_st = s - 1 >= z0;                // plane s - 1 is stored
         const bool blk_next = s + 1 >= z0 && s + 1 < z1;
         const int qb0 = (c0 + 1 + y0 + s) & 1;          // x-parity of the black point of row 0 in plane s
-        __builtin_amdgcn_s_setprio(3);
-        // ---- stores of the previous step's results
-        if (red_st && !a_nost) {
-            real* p = vout + (size_t)(zr - 1) * g.PL;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int qr = q ^ 1 ^ (r & 1);  // q already belongs to plane zr
-                if (lane_on && (qr | j) && r < nrows) {
-                    // the rows a neighbouring workgroup reads in this launch go to memory write-through
-                    const bool shared = (wy == 0 && r == 0 && by > 0) || (wy == WY - 1 && r == R - 1 && by < gy - 1);
-                    if (shared && !a_nosc) st_sc1(&p[roff[r] + qr * H + j], op[r]);
-                    else __builtin_nontemporal_store(op[r], &p[roff[r] + qr * H + j]);
-                }
-            }
-        }
-        if (blk_st && !a_nost) {
-            real* p = vout + (size_t)(s - 1) * g.PL;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int qb = qb0 ^ 1 ^ (r & 1);
-                if (lane_on && (qb | j) && r < nrows) __builtin_nontemporal_store(obp[r], &p[roff[r] + qb * H + j]);
-            }
-        }
-        // ---- red stage: loads of the next step
-        if (red_more) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int qn = q ^ 1 ^ (r & 1);
-                cn[r] = pv[roff[r] + 2 * sxy + qn * H + j];
-                fn[r] = (FNT ? __builtin_nontemporal_load(&pf[roff[r] + sxy + qn * H + j]) : pf[roff[r] + sxy + qn * H + j]);
-            }
-            MGX_LOAD_RIM(1, q ^ 1, xn, Nn, Sn);
-        }
-        // ---- black stage: loads of the next step (plane s + 1)
-        if (blk_next) {
-            const int qn0 = qb0 ^ 1;  // row 0's black parity in plane s + 1
-            const real* pfb = f + (size_t)(s + 1) * g.PL;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int qb = qn0 ^ (r & 1);
-                fbn[r] = (FNT ? __builtin_nontemporal_load(&pfb[roff[r] + qb * H + j]) : pfb[roff[r] + qb * H + j]);
-            }
-            const real* pi = vin + (size_t)(s + 1) * g.PL;
-            if (rimR) {  // E neighbour of x = sx - 2: the boundary column (index M - 1 of half 0), never written
-#pragma unroll
-                for (int r = 0; r < R; r++) xbn[r] = pi[roff[r] + jv + 1];  // index M - 1, through jv: see there
-            }
-            if (s + 1 == 1 || s + 1 == sz - 2) {  // the plane below / above is a boundary plane: its entries as they are in memory
-                const real* pz = vin + (s + 1 == 1 ? (size_t)0 : (size_t)(sz - 1) * g.PL);
-#pragma unroll
-                for (int r = 0; r < R; r++) zbn[r] = pz[roff[r] + (qn0 ^ (r & 1)) * H + j];
-            }
+        // The pieces of a step.  PHASED order (ILV = 0): all memory instructions first, then the arithmetic of both stages.
+        // INTERLEAVED order (ILV = 1): the same pieces, memory instructions in groups between the rows of the arithmetic, so that
+        // the CU's memory pipe has requests queued while waves compute (in the phased order the pipe
+        // idles during the arithmetic, and the arithmetic waits during the issue phase, for every wave at once).
+        const int qn0 = qb0 ^ 1;  // row 0's black parity in plane s + 1
+#define MGX_P_STORE_RED                                                                                                       \
+    if (red_st && !a_nost) {                                                                                                  \
+        real* p = vout + (size_t)(zr - 1) * g.PL;                                                                             \
+        _Pragma("unroll") for (int r = 0; r < R; r++) {                                                                       \
+            const int qr = q ^ 1 ^ (r & 1); /* q already belongs to plane zr */                                               \
+            if (lane_on && (qr | j) && r < nrows) {                                                                           \
+                /* the rows a neighbouring workgroup reads in this launch go to memory write-through */                      \
+                const bool shared = (wy == 0 && r == 0 && by > 0) || (wy == WY - 1 && r == R - 1 && by < gy - 1);             \
+                if (shared && !a_nosc) st_sc1(&p[roff[r] + qr * H + j], op[r]);                                               \
+                else __builtin_nontemporal_store(op[r], &p[roff[r] + qr * H + j]);                                            \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    }
+#define MGX_P_STORE_BLK                                                                                                       \
+    if (blk_st && !a_nost) {                                                                                                  \
+        real* p = vout + (size_t)(s - 1) * g.PL;                                                                              \
+        _Pragma("unroll") for (int r = 0; r < R; r++) {                                                                       \
+            const int qb = qb0 ^ 1 ^ (r & 1);                                                                                 \
+            if (lane_on && (qb | j) && r < nrows) __builtin_nontemporal_store(obp[r], &p[roff[r] + qb * H + j]);              \
+        }                                                                                                                     \
+    }
+#define MGX_P_LOAD_CN                                                                                                         \
+    if (red_more) {                                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < R; r++) cn[r] = pv[roff[r] + 2 * sxy + (q ^ 1 ^ (r & 1)) * H + j];              \
+        MGX_LOAD_RIM(1, q ^ 1, xn, Nn, Sn);                                                                                   \
+    }
+#define MGX_P_LOAD_FN                                                                                                         \
+    if (red_more) {                                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < R; r++) {                                                                       \
+            const int qn = q ^ 1 ^ (r & 1);                                                                                   \
+            fn[r] = (FNT ? __builtin_nontemporal_load(&pf[roff[r] + sxy + qn * H + j]) : pf[roff[r] + sxy + qn * H + j]);     \
+        }                                                                                                                     \
+    }
+        // loads of the black stage's next step (plane s + 1): f, the boundary column / planes, and -- behind the neighbour's
+        // progress word, polled a step ago -- its red rim row
+#define MGX_P_LOAD_BLK                                                                                                        \
+    if (blk_next) {                                                                                                           \
+        const real* pfb = f + (size_t)(s + 1) * g.PL;                                                                         \
+        _Pragma("unroll") for (int r = 0; r < R; r++) {                                                                       \
+            const int qb = qn0 ^ (r & 1);                                                                                     \
+            fbn[r] = (FNT ? __builtin_nontemporal_load(&pfb[roff[r] + qb * H + j]) : pfb[roff[r] + qb * H + j]);              \
+        }                                                                                                                     \
+        const real* pi = vin + (size_t)(s + 1) * g.PL;                                                                        \
+        if (rimR) { /* E neighbour of x = sx - 2: the boundary column (index M - 1 of half 0), never written */              \
+            _Pragma("unroll") for (int r = 0; r < R; r++) xbn[r] = pi[roff[r] + jv + 1]; /* through jv: see there */          \
+        }                                                                                                                     \
+        if (s + 1 == 1 || s + 1 == sz - 2) { /* the plane below / above is a boundary plane: its entries as they are */      \
+            const real* pz = vin + (s + 1 == 1 ? (size_t)0 : (size_t)(sz - 1) * g.PL);                                        \
+            _Pragma("unroll") for (int r = 0; r < R; r++) zbn[r] = pz[roff[r] + (qn0 ^ (r & 1)) * H + j];                     \
+        }                                                                                                                     \
+        MGX_STAMP(0);                                                                                                         \
+        if (dep && !a_nowait) {                                                                                               \
+            const u64 need = epbase + (u64)(s + 2);                                                                           \
+            u64 pv_ = __builtin_amdgcn_readfirstlane((unsigned)(pollv >> 32));                                                \
+            pv_ = (pv_ << 32) | (u64)__builtin_amdgcn_readfirstlane((unsigned)pollv);                                         \
+            unsigned spins = 0;                                                                                               \
+            while (pv_ < need && !gave_up) {                                                                                  \
+                __builtin_amdgcn_s_sleep(8);                                                                                  \
+                const u64 t_ = ld_sc1(dep);                                                                                   \
+                pv_ = __builtin_amdgcn_readfirstlane((unsigned)(t_ >> 32));                                                   \
+                pv_ = (pv_ << 32) | (u64)__builtin_amdgcn_readfirstlane((unsigned)t_);                                        \
+                if (++spins > SWEEP_SPIN_LIMIT ||                                                                             \
+                    ((spins & 1023u) == 0 && __hip_atomic_load(sync.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) { \
+                    if (lane == 0) __hip_atomic_store(sync.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);           \
+                    gave_up = true;                                                                                           \
+                }                                                                                                             \
+            }                                                                                                                 \
+            asm volatile("" ::: "memory"); /* the rim loads stay behind the poll */                                           \
+        }                                                                                                                     \
+        MGX_STAMP(1);                                                                                                         \
+        real* po_ = vout + (size_t)(s + 1) * g.PL;                                                                            \
+        if (Nmem) {                                                                                                           \
+            if (NfromNb && !a_nosc) Nbn = ld_sc1(&po_[roffN + qn0 * H + j]);                                                  \
+            else Nbn = pi[roffN + qn0 * H + j];                                                                               \
+        }                                                                                                                     \
+        if (Smem) {                                                                                                           \
+            const int qs = qn0 ^ (rl & 1);                                                                                    \
+            if (SfromNb && !a_nosc) Sbn = ld_sc1(&po_[roffSb + qs * H + j]);                                                  \
+            else Sbn = pi[roffSb + qs * H + j];                                                                               \
+        }                                                                                                                     \
+    }                                                                                                                         \
+    if (dep && s + 2 >= z0 && s + 2 < z1) pollv = ld_sc1(dep); /* for the next step's check */
+        // red stage, plane zr: row r of this lane
+        const real Nl_ = red_c ? ey[es_c][wyN][wx][1][lane] : (real)0, Sl_ = red_c ? ey[es_c][wyS][wx][0][lane] : (real)0;
+        const real Nedge = wy > 0 ? Nl_ : Nc;
+        const real Sedge = wy < WY - 1 ? Sl_ : Sc;
+        real* const rs = ringp + sl_r * (TY * TX) + mycell;
+#define MGX_P_RED_ROW(r)                                                                                                      \
+    if (red_c) {                                                                                                              \
+        const int qr = q ^ ((r)&1);                                                                                           \
+        const real fromR = ex[es_c][wy][wxR][0][r], fromL = ex[es_c][wy][wxL][1][r];                                          \
+        real nb = qr ? __shfl_down(cc[r], 1, 64) : __shfl_up(cc[r], 1, 64);                                                   \
+        if (qr) {                                                                                                             \
+            if (lane == 63) nb = fromR;                                                                                       \
+            if (rimR) nb = xc[r];                                                                                             \
+        } else {                                                                                                              \
+            if (lane == 0) nb = fromL;                                                                                        \
+            if (rimL) nb = xc[r]; /* x = 0: not a neighbour but the point itself; the result is not used */                  \
+        }                                                                                                                     \
+        const real W = qr ? cc[r] : nb;                                                                                       \
+        const real E = qr ? nb : cc[r];                                                                                       \
+        const real N = (r) == 0 ? Nedge : cc[(r) > 0 ? (r)-1 : 0];                                                            \
+        const real S = (r) == R - 1 ? Sedge : cc[(r) < R - 1 ? (r) + 1 : 0];                                                  \
+        oc[r] = a_nored ? W + E + N + S + cp[r] + cu[r] + fc[r]                                                               \
+                        : relax3d_point_rd<real>(W, E, N, S, cp[r], cu[r], fc[r], hx2, hy2, hz2, rd);                         \
+        rs[(r)*TX] = (qr | j) ? oc[r] : xc[r]; /* x = 0 keeps its boundary value */                                          \
+    }
+        // black stage, plane s
+        const real* const rb = ringp + sl_b * (TY * TX) + mycell;
+        const real* const ru = ringp + sl_u * (TY * TX) + mycell;
+        real U[R];
+        real Nring = 0, Sring = 0;
+#define MGX_P_BLK_PRE                                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < R; r++) U[r] = ru[r * TX]; /* red plane s + 1, own entry (written D - 1 steps ago) */ \
+    if (blk_c) {                                                                                                              \
+        if (wy > 0) Nring = rb[-TX];                                                                                          \
+        if (wy < WY - 1) Sring = rb[R * TX];                                                                                  \
+    }
+#define MGX_P_BLK_ROW(r)                                                                                                      \
+    if (blk_c) {                                                                                                              \
+        const int qb = qb0 ^ ((r)&1);                                                                                         \
+        real side = qb ? rb[(r)*TX + (jn < TX - 1 ? 1 : 0)] : rb[(r)*TX - (jn > 0 ? 1 : 0)];                                  \
+        if (qb && rimR) side = xb[r];                                                                                         \
+        const real Wv = qb ? Pw[r] : side;                                                                                    \
+        const real Ev = qb ? side : Pw[r];                                                                                    \
+        real Nv = (r) == 0 ? (Nmem ? Nb : Nring) : Pw[(r) > 0 ? (r)-1 : 0];                                                   \
+        real Sv = (r) == R - 1 ? Sring : Pw[(r) < R - 1 ? (r) + 1 : 0];                                                       \
+        if (Smem && (r) == rl) Sv = Sb;                                                                                       \
+        const real Dv = s == 1 ? zb[r] : Dw[r];                                                                               \
+        const real Uv = s == sz - 2 ? zb[r] : U[r];                                                                           \
+        ob[r] = a_noblk ? Wv + Ev + Nv + Sv + Dv + Uv + fb[r]                                                                 \
+                        : relax3d_point_rd<real>(Wv, Ev, Nv, Sv, Dv, Uv, fb[r], hx2, hy2, hz2, rd);                           \
+    }
+#define MGX_P_BLK_POST                                 \
+    _Pragma("unroll") for (int r = 0; r < R; r++) {   \
+        Dw[r] = Pw[r];                                 \
+        Pw[r] = U[r];                                  \
+    }
+#define MGX_SCHED __builtin_amdgcn_sched_barrier(0)
+        if constexpr (!ILV) {
+            __builtin_amdgcn_s_setprio(3);
+            MGX_P_STORE_RED
+            MGX_P_STORE_BLK
+            MGX_P_LOAD_CN
+            MGX_P_LOAD_FN
+            MGX_P_LOAD_BLK
+            if (red_more) publish(es_n, cu);
+            __builtin_amdgcn_s_setprio(0);
             MGX_STAMP(0);
-            if (dep && !a_nowait) {
-                // the neighbour's red rim row of plane s + 1 must be in memory: its progress word, polled a step ago
-                const u64 need = epbase + (u64)(s + 2);
-                u64 pv_ = __builtin_amdgcn_readfirstlane((unsigned)(pollv >> 32));
-                pv_ = (pv_ << 32) | (u64)__builtin_amdgcn_readfirstlane((unsigned)pollv);
-                unsigned spins = 0;
-                while (pv_ < need && !gave_up) {
-                    __builtin_amdgcn_s_sleep(8);
-                    const u64 t_ = ld_sc1(dep);
-                    pv_ = __builtin_amdgcn_readfirstlane((unsigned)(t_ >> 32));
-                    pv_ = (pv_ << 32) | (u64)__builtin_amdgcn_readfirstlane((unsigned)t_);
-                    if (++spins > SWEEP_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(sync.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
-                        if (lane == 0) __hip_atomic_store(sync.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        gave_up = true;
-                    }
-                }
-                asm volatile("" ::: "memory");  // the rim loads stay behind the poll
+#pragma unroll
+            for (int r = 0; r < R; r++) { MGX_P_RED_ROW(r) }
+            MGX_STAMP(2);
+            MGX_P_BLK_PRE
+#pragma unroll
+            for (int r = 0; r < R; r++) { MGX_P_BLK_ROW(r) }
+            MGX_P_BLK_POST
+        } else {
+            static_assert(!ILV || R == 4 || R == 2, "interleaved order is written for 2 or 4 rows per lane");
+            MGX_P_STORE_RED
+            MGX_P_LOAD_CN
+            MGX_SCHED;
+            MGX_P_RED_ROW(0)
+            MGX_SCHED;
+            MGX_P_LOAD_FN
+            MGX_SCHED;
+            MGX_P_RED_ROW(1)
+            MGX_SCHED;
+            MGX_P_LOAD_BLK
+            MGX_SCHED;
+            if constexpr (R == 4) {
+                MGX_P_RED_ROW(2)
+                MGX_SCHED;
+                MGX_P_STORE_BLK
+                MGX_SCHED;
+                MGX_P_RED_ROW(3)
+            } else {
+                MGX_P_STORE_BLK
             }
-            MGX_STAMP(1);
-            real* po_ = vout + (size_t)(s + 1) * g.PL;
-            if (Nmem) {
-                if (NfromNb && !a_nosc) Nbn = ld_sc1(&po_[roffN + qn0 * H + j]);
-                else Nbn = pi[roffN + qn0 * H + j];
-            }
-            if (Smem) {
-                const int qs = qn0 ^ (rl & 1);
-                if (SfromNb && !a_nosc) Sbn = ld_sc1(&po_[roffSb + qs * H + j]);
-                else Sbn = pi[roffSb + qs * H + j];
-            }
+            if (red_more) publish(es_n, cu);
+            MGX_SCHED;
+            MGX_STAMP(2);
+            MGX_P_BLK_PRE
+#pragma unroll
+            for (int r = 0; r < R; r++) { MGX_P_BLK_ROW(r) }
+            MGX_P_BLK_POST
         }
-        if (dep && s + 2 >= z0 && s + 2 < z1) pollv = ld_sc1(dep);  // for the next step's check
-        if (red_more) publish(es_n, cu);
-        __builtin_amdgcn_s_setprio(0);
-        MGX_STAMP(0);
-
-        // ---- red stage: plane zr
-        if (red_c) {
-            const int slot = es_c;
-            const real Nl = ey[slot][wyN][wx][1][lane], Sl = ey[slot][wyS][wx][0][lane];
-            const real Nedge = wy > 0 ? Nl : Nc;
-            const real Sedge = wy < WY - 1 ? Sl : Sc;
-            real* rs = ringp + sl_r * (TY * TX) + mycell;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int qr = q ^ (r & 1);
-                const real fromR = ex[slot][wy][wxR][0][r], fromL = ex[slot][wy][wxL][1][r];
-                real nb = qr ? __shfl_down(cc[r], 1, 64) : __shfl_up(cc[r], 1, 64);
-                if (qr) {
-                    if (lane == 63) nb = fromR;
-                    if (rimR) nb = xc[r];
-                } else {
-                    if (lane == 0) nb = fromL;
-                    if (rimL) nb = xc[r];  // x = 0: not a neighbour but the point itself; the result is not used
-                }
-                const real W = qr ? cc[r] : nb;
-                const real E = qr ? nb : cc[r];
-                const real N = r == 0 ? Nedge : cc[r - 1];
-                const real S = r == R - 1 ? Sedge : cc[r + 1];
-                oc[r] = a_nored ? W + E + N + S + cp[r] + cu[r] + fc[r] : relax3d_point_rd<real>(W, E, N, S, cp[r], cu[r], fc[r], hx2, hy2, hz2, rd);
-                rs[r * TX] = (qr | j) ? oc[r] : xc[r];  // x = 0 keeps its boundary value
-            }
-        }
-        MGX_STAMP(2);
-        // ---- black stage: plane s
-        {
-            const real* rb = ringp + sl_b * (TY * TX) + mycell;
-            const real* ru = ringp + sl_u * (TY * TX) + mycell;
-            real U[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) U[r] = ru[r * TX];  // red plane s + 1, own entry (written D - 1 steps ago by this lane)
-            if (blk_c) {
-                const real Nring = wy > 0 ? rb[-TX] : (real)0;
-                const real Sring = wy < WY - 1 ? rb[R * TX] : (real)0;
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int qb = qb0 ^ (r & 1);
-                    real side = qb ? rb[r * TX + (jn < TX - 1 ? 1 : 0)] : rb[r * TX - (jn > 0 ? 1 : 0)];
-                    if (qb && rimR) side = xb[r];
-                    const real Wv = qb ? Pw[r] : side;
-                    const real Ev = qb ? side : Pw[r];
-                    real Nv = r == 0 ? (Nmem ? Nb : Nring) : Pw[r - 1];
-                    real Sv = r == R - 1 ? Sring : Pw[r + 1];
-                    if (Smem && r == rl) Sv = Sb;
-                    const real Dv = s == 1 ? zb[r] : Dw[r];
-                    const real Uv = s == sz - 2 ? zb[r] : U[r];
-                    ob[r] = a_noblk ? Wv + Ev + Nv + Sv + Dv + Uv + fb[r] : relax3d_point_rd<real>(Wv, Ev, Nv, Sv, Dv, Uv, fb[r], hx2, hy2, hz2, rd);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                Dw[r] = Pw[r];
-                Pw[r] = U[r];
-            }
-        }
+#undef MGX_P_STORE_RED
+#undef MGX_P_STORE_BLK
+#undef MGX_P_LOAD_CN
+#undef MGX_P_LOAD_FN
+#undef MGX_P_LOAD_BLK
+#undef MGX_P_RED_ROW
+#undef MGX_P_BLK_PRE
+#undef MGX_P_BLK_ROW
+#undef MGX_P_BLK_POST
+#undef MGX_SCHED
         MGX_STAMP(3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         MGX_STAMP(4);
@@ -671,17 +725,31 @@ static int sweep3d_launch_shape(mgx_ctx* ctx, const real* vin, real* vout, const
     const bool fnt = (size_t)sx * sy * (size_t)sz * sizeof(real) > ((size_t)256 << 20);
     const dim3 grid((unsigned)gy * gz), block(64, WX * WY, 1);
     const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
-    snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "sweep3d_xs_kernel<%s,%d,%d,%d,%d,%s>", sizeof(real) == 8 ? "double" : "float",
-             WX, WY, R, D, fnt ? "true" : "false");
+    snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "sweep3d_xs_kernel<%s,%d,%d,%d,%d,%s%s>", sizeof(real) == 8 ? "double" : "float",
+             WX, WY, R, D, fnt ? "true" : "false", ctx->sweep_ilv ? ",0,true" : "");
 #ifdef MGX_DIAGNOSTICS
     if (ctx->sweep_dbg) {  // cycle stamps / ablations (tools/sweep_stamps.py)
         void* ws = nullptr;
         MGX_TRY_RET(workspace(ctx, (size_t)gy * gz * WX * WY * 8 * sizeof(long long), &ws));
-        hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, true, 1>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb, ze,
-                           hx2, hy2, hz2, c0, zchunk, gy, xcd, sync, (long long*)ws, ctx->sweep_dbg >> 1);
+        if (ctx->sweep_ilv)
+            hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, true, 1, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb,
+                               ze, hx2, hy2, hz2, c0, zchunk, gy, xcd, sync, (long long*)ws, ctx->sweep_dbg >> 1);
+        else
+            hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, true, 1>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb, ze,
+                               hx2, hy2, hz2, c0, zchunk, gy, xcd, sync, (long long*)ws, ctx->sweep_dbg >> 1);
         return MGX_OK;
     }
 #endif
+    long long* const nodbg = nullptr;
+    if (ctx->sweep_ilv) {  // memory instructions interleaved with the arithmetic ("relax3d.fused_ilv")
+        if (fnt)
+            hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, true, 0, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb,
+                               ze, hx2, hy2, hz2, c0, zchunk, gy, xcd, sync, nodbg, 0);
+        else
+            hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, false, 0, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb,
+                               ze, hx2, hy2, hz2, c0, zchunk, gy, xcd, sync, nodbg, 0);
+        return MGX_OK;
+    }
     if (fnt)
         hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb, ze, hx2,
                            hy2, hz2, c0, zchunk, gy, xcd, sync);

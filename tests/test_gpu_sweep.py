@@ -63,18 +63,39 @@ def test_sweep_run_lengths(ctx, zchunk):
     assert bits_equal(got, want)
 
 
+@pytest.mark.parametrize("ilv", [0, 1])
 @pytest.mark.parametrize("lead", [5, 6, 7])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_sweep_leads(ctx, lead, dtype):
+def test_sweep_leads_and_instruction_orders(ctx, lead, dtype, ilv):
+    """the lead of the red stage, and both orders of a step's instructions (memory instructions first / in groups between the
+    rows of the arithmetic)"""
     n3 = (513, 257, 129)
     v, f = _data(n3, dtype, seed=lead)
     ctx.set_param("relax3d.fused_lead", lead)
+    ctx.set_param("relax3d.fused_ilv", ilv)
     try:
         got = P.ops3dxs.relax_pp(ctx, v, f, n3, RG, 4)
         ctx.sync()
     finally:
         ctx.set_param("relax3d.fused_lead", 0)
+        ctx.set_param("relax3d.fused_ilv", 0)
     assert bits_equal(got, O.relax3d(n3, RG, v, f, 4, dtype=dtype))
+
+
+@pytest.mark.parametrize("zchunk", [3, 9, 33])
+def test_sweep_interleaved_order_run_lengths(ctx, zchunk):
+    n3 = (513, 129, 129)
+    v, f = _data(n3, np.float64, seed=40 + zchunk)
+    ctx.set_param("relax3d.fused_ilv", 1)
+    ctx.set_param("relax3d.zchunk", zchunk if zchunk >= 8 else 8)
+    try:
+        got = P.ops3dxs.relax_pp(ctx, v, f, n3, RG, 3)
+        ctx.sync()
+        assert "true" in ctx.last_relax_kernel().split(",")[-1]
+    finally:
+        ctx.set_param("relax3d.zchunk", 0)
+        ctx.set_param("relax3d.fused_ilv", 0)
+    assert bits_equal(got, O.relax3d(n3, RG, v, f, 3, dtype=np.float64))
 
 
 def test_sweep_off_switch_and_small_levels(ctx):

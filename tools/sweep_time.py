@@ -32,12 +32,13 @@ def timed(fn):
 
 
 pts = float(n - 2) ** 3
-for fused, lead in [(0, 0)] + [(1, l) for l in leads] + [(0, 0)]:
+for fused, lead, ilv in [(0, 0, 0)] + [(1, l, i) for l in leads for i in (0, 1)] + [(0, 0, 0)]:
     ctx.set_param("relax3d.fused", fused)
     ctx.set_param("relax3d.fused_lead", lead)
+    ctx.set_param("relax3d.fused_ilv", ilv)
     med, best = timed(lambda: mg.Relax(0, 2))
     ctx.sync()
-    print("n=%d %s fused=%d lead=%d: Relax(2) median %.4f ms (min %.4f) = %.4f ms per sweep, %.1f GLUPS  [%s]" % (
-        n, np.dtype(dtype).name, fused, lead, med, best, med / 2, 2 * pts / med / 1e6, ctx.last_relax_kernel()), flush=True)
+    print("n=%d %s fused=%d lead=%d ilv=%d: Relax(2) median %.4f ms (min %.4f) = %.4f ms per sweep, %.1f GLUPS  [%s]" % (
+        n, np.dtype(dtype).name, fused, lead, ilv, med, best, med / 2, 2 * pts / med / 1e6, ctx.last_relax_kernel()), flush=True)
 mg.close()
 ctx.close()
