@@ -93,12 +93,17 @@ int mgx_ctx_device(const mgx_ctx* ctx, int* device);
  * "relax3d.zero_first", "relax3d.small" 0/1 switches of the fused forms; "residual_restrict3d.stream" 0..3 kernel choice,
  * ".pzchunk" coarse planes per run (0 automatic), ".tyw" waves per workgroup, ".cr" coarse rows per lane, ".rows" fine rows
  * per wave of the pipelined kernel (0 = by level size, 2, 4), ".xcd" 0/1/2 XCD-aware block order, ".rcp" 0/1: with
- * power-of-two squared spacings the residual multiplies by the exact reciprocals instead of dividing (same bits).
+ * power-of-two squared spacings the residual multiplies by the exact reciprocals instead of dividing (same bits);
+ * "rr3d.black" 0 / 1 / 2: the last black pass of the pre-smoothing inside the residual+restrict launch -- off / on the
+ * HBM-bound levels / wherever the geometry allows (tests), "rr3d.black_waves" 0 (by precision), 12, 16 waves per workgroup.
  * Unknown names and out-of-range values are rejected (MGX_ERR_INVALID). */
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value);
 /* name (kernel<template arguments>) of the smoother kernel the most recent 3D x-split colour pass launched; "" if none.
  * bench.py reports it as roofline.kernel so that the PMC traffic figure is attached only to the kernel it was taken from */
 const char* mgx_ctx_last_relax_kernel(const mgx_ctx* ctx);
+/* name of the kernel that ran the last black pass together with residual + restrict in the most recent
+ * mgx3dxs_smooth_residual_restrict_* call; "" when that call ran the operators one after the other */
+const char* mgx_ctx_last_rr_kernel(const mgx_ctx* ctx);
 /* raw hipStream_t of the compute stream (for callers that bring their own HIP code) */
 int mgx_ctx_stream(const mgx_ctx* ctx, void** hip_stream);
 
@@ -305,6 +310,16 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     int mgx3dxs_interpolate_correct_relax_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3],   \
                                                 const real h[3], const real* coarse_v, const int cn[3], \
                                                 int ncycles);                                           \
+    /* smooth_residual_restrict: the way down on one level in one call -- Relax(ncycles) (from_zero != 0: */ \
+    /* on v = 0 as relax_from_zero, v_rim_is_zero as there), CalculateResidual, Restrict                  */ \
+    /* (N3/MultiGrid3D.cpp:626-632; coarse_rim_is_zero as residual_restrict_keep_rim).  On the HBM-bound */ \
+    /* levels the LAST BLACK PASS runs inside the residual+restrict launch (the black values are relaxed  */ \
+    /* one plane ahead of the residual and stored on the way; "rr3d.black" = 0 turns that off); v and     */ \
+    /* coarse_f are bit-identical to relax followed by residual_restrict.                                 */ \
+    int mgx3dxs_smooth_residual_restrict_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3],    \
+                                               const real h[3], int ncycles, int from_zero,             \
+                                               int v_rim_is_zero, int mode, real* coarse_f,             \
+                                               const int cn[3], int coarse_rim_is_zero);                \
     /* The same on a z-slab (the post-smoothing of the slab-decomposed cycle), in its two pieces.  n / cn */ \
     /* are GLOBAL sizes, v / f start at global plane fzoff (even), coarse_v at global plane czoff and     */ \
     /* holds cplanes planes.  corr_fused_takes: 1 when a level with these rows and `nplanes` planes to    */ \

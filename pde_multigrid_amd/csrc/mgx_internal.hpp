@@ -31,6 +31,10 @@ struct mgx_ctx {
     int relax_lds = -1;  // smoother kernel choice: -1 automatic, 0 relax3d_xs_kernel, shape codes see relax3d_xs_pass_lds
     int rr_cr = 0, rr_tyw = 4;  // streaming residual+restrict: coarse rows per lane, waves per block
     int rr_pzchunk = 0;    // coarse planes per block of residual_restrict3d_kernel, 0 = automatic
+    int rr_black = 1;      // the last black pass of the pre-smoothing inside the residual+restrict launch (mgx_relax_rr3d.hip):
+                           // 0 off, 1 on the HBM-bound levels, 2 wherever the geometry allows (tests)
+    int rr_black_abl = 0;  // diagnostic builds: ablation bits of that kernel (timing only, WRONG results)
+    int rr_black_waves = 0;  // its waves per workgroup: 0 = by precision, 12, 16
     int relax_zero_first = 1;  // relax_from_zero: the first red pass on a zeroed level does not read v (and nothing is filled)
     int relax_v2 = 1;      // fp32 smoother on wide levels: two x-pairs per lane (8-byte loads)
     int corr_fuse = 1;     // interpolate_correct_relax3d: the first red pass applies the coarse-grid correction on the fly
@@ -54,6 +58,7 @@ struct mgx_ctx {
     void* rehearse_buf = nullptr;  // its scratch: the partner buffer of a send / receive that has none on this rank
     size_t rehearse_bytes = 0;
     int num_cus = 256;
+    char last_rr_kernel[96] = "";     // the fused black pass + residual + restrict kernel of the most recent call ("" = not fused)
     char last_relax_kernel[96] = "";  // name of the smoother kernel of the most recent colour pass (bench.py: roofline.kernel)
 };
 

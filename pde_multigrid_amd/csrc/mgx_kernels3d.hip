@@ -1433,20 +1433,6 @@ __global__ void __launch_bounds__(256) residual_restrict3d_kernel(const real* __
     }
 }
 
-// block -> tile of a 1-D launch over gx x gy x gz tiles (x fastest).  xcd_mode 1: consecutive blocks go to the eight XCDs
-// in turn, so every XCD is given one contiguous run of the tile order -- workgroups whose tiles share rows or cache lines
-// then share an L2 (see relax3d_xs_kernel); xcd_mode 0: plain order.
-__device__ __forceinline__ void tile_of_block(int xcd_mode, int gx, int gy, int& bx, int& by, int& bz) {
-    unsigned b = blockIdx.x;
-    if (xcd_mode == 1) {
-        const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
-        b = k * per + (k < rem ? k : rem) + (b >> 3);
-    }
-    bx = b % gx;
-    by = (b / gx) % gy;
-    bz = b / (gx * gy);
-}
-
 // ------------------------------------------------------------------ residual + restrict, streaming (XSplit)
 // Lane i of a wave owns the fine x-pair {2i, 2i+1} (= coarse column i) of the 2*CR+3 fine rows around CR
 // consecutive coarse rows and marches through a chunk of coarse planes.  v is carried in registers along z
@@ -1579,29 +1565,6 @@ __global__ void __launch_bounds__(64 * TYW)
 // after its third residual plane (2pz+1), when the neighbour's residual rows are visible.  Lanes 0 and 63 are halo
 // lanes (62 coarse columns per wave, nobody loads a foreign column).  Expressions and association: those of
 // residual_restrict3d_xs_kernel.
-template <class real>
-__device__ __forceinline__ real wave_from_prev_lane(real x) {  // lane i gets lane i-1 (lane 0 keeps its own)
-    if constexpr (sizeof(real) == 8) {
-        int lo = __double2loint(x), hi = __double2hiint(x);
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
-        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
-        return __hiloint2double(hi, lo);
-    } else {
-        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xf, 0xf, false));
-    }
-}
-template <class real>
-__device__ __forceinline__ real wave_from_next_lane(real x) {  // lane i gets lane i+1 (lane 63 keeps its own)
-    if constexpr (sizeof(real) == 8) {
-        int lo = __double2loint(x), hi = __double2hiint(x);
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
-        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-        return __hiloint2double(hi, lo);
-    } else {
-        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130, 0xf, 0xf, false));
-    }
-}
-
 template <class real, int MODE, int TYW, int OWN = 4>
 __global__ void __launch_bounds__(64 * TYW)
     residual_restrict3d_xs_pipe_kernel(const real* __restrict__ v, const real* __restrict__ f, int sx, int sy, int szg,
@@ -2367,6 +2330,52 @@ int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[
     return MGX_OK;
 }
 
+bool relax_rr3d_xs_takes(const mgx_ctx* ctx, const int n[3], const int cn[3]);  // mgx_relax_rr3d.hip
+template <class real>
+bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int mode, bool rcp,
+                          real* coarse_f, const int cn[3]);
+
+// The way down on one level: Relax(ncycles) (from_zero: on v = 0, as relax3d_from_zero), CalculateResidual, Restrict
+// (N3/MultiGrid3D.cpp:626-632).  Where the level takes it the last black pass runs inside the residual+restrict launch
+// (relax_rr3d_xs_kernel); otherwise the operators are called one after the other.
+template <class real>
+int smooth_residual_restrict3d_xs(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3], int ncycles, int from_zero,
+                                  int v_rim_is_zero, int mode, real* coarse_f, const int cn[3], int coarse_rim_is_zero) {
+    MGX_REQUIRE(ctx && v && f && h && coarse_f, MGX_ERR_INVALID, "smooth_residual_restrict3d: NULL argument");
+    MGX_USE(ctx);
+    int st = check_n3(n, "smooth_residual_restrict3d");
+    if (st) return st;
+    st = check_coarse3(n, cn, "smooth_residual_restrict3d");
+    if (st) return st;
+    MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "smooth_residual_restrict3d: ncycles = %d < 0", ncycles);
+    MGX_REQUIRE(mode == MGX_RESIDUAL_REF_COMPAT || mode == MGX_RESIDUAL_CORRECT, MGX_ERR_INVALID,
+                "smooth_residual_restrict3d: bad mode %d", mode);
+    ctx->last_rr_kernel[0] = 0;
+    if (ncycles < 1 || !relax_rr3d_xs_takes(ctx, n, cn)) {
+        st = from_zero ? relax3d_from_zero<real, XSplit>(ctx, v, f, n, h, ncycles, v_rim_is_zero) : relax3d<real, XSplit>(ctx, v, f, n, h, ncycles);
+        if (st) return st;
+        return residual_restrict3d<real, XSplit>(ctx, v, f, n, h, mode, coarse_f, cn, coarse_rim_is_zero != 0);
+    }
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // :498-500
+    int s = 0;
+    if (from_zero) {
+        if (v_rim_is_zero && ctx->relax_zero_first) {  // relax3d_from_zero: the first red pass does not read v
+            hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, XSplit>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2),
+                               blk(), 0, ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0, 1);
+            s = 1;
+        } else {
+            MGX_TRY_RET(fill_zero(ctx, v, Geo<XSplit, real>(n[0], n[1]).PL * (size_t)n[2] * sizeof(real)));
+        }
+    }
+    for (; s < 2 * ncycles - 1; s++) relax3d_xs_pass<real>(ctx, v, f, n[0], n[1], 1, n[2] - 1, hx2, hy2, hz2, s & 1);
+    if (!coarse_rim_is_zero) MGX_TRY_RET(fill_zero(ctx, coarse_f, Geo<XSplit, real>(cn[0], cn[1]).PL * (size_t)cn[2] * sizeof(real)));
+    const bool rcp = ctx->rr_rcp && exact_reciprocal(hx2) && exact_reciprocal(hy2) && exact_reciprocal(hz2);
+    MGX_REQUIRE(relax_rr3d_xs_launch<real>(ctx, v, f, n, hx2, hy2, hz2, mode, rcp, coarse_f, cn), MGX_ERR_INVALID,
+                "smooth_residual_restrict3d: the fused launch refused a level it had accepted");
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
 template <class real, class L>
 int init_f3d(mgx_ctx* ctx, real* f, const int n[3], double c, const double* tx, const double* ty, const double* tz) {
     MGX_REQUIRE(ctx && f && tx && ty && tz, MGX_ERR_INVALID, "init_f3d: NULL argument");
@@ -2911,6 +2920,13 @@ template int relax3d_xs_from_zero<double>(mgx_ctx*, double*, const double*, cons
                                                 int ncycles) {                                                   \
         return mgx::interpolate_correct_relax3d_xs<real>(ctx, v, f, n, h, coarse_v, cn, ncycles);                \
     }                                                                                                            \
+    int mgx3dxs_smooth_residual_restrict_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3],            \
+                                               const real h[3], int ncycles, int from_zero, int v_rim_is_zero,   \
+                                               int mode, real* coarse_f, const int cn[3],                        \
+                                               int coarse_rim_is_zero) {                                         \
+        return mgx::smooth_residual_restrict3d_xs<real>(ctx, v, f, n, h, ncycles, from_zero, v_rim_is_zero, mode, \
+                                                        coarse_f, cn, coarse_rim_is_zero);                       \
+    }                                                                                                            \
     int mgx3dxs_corr_fused_takes_##SFX(const mgx_ctx* ctx, const int n[3], int nplanes) {                        \
         return ctx && n && mgx::corr_fused_takes(ctx, n[0], n[1], n[2], nplanes);                                \
     }                                                                                                            \
@@ -2954,6 +2970,7 @@ MGX_DEFINE_MISC3D(f32, float)
 MGX_DEFINE_MISC3D(f64, double)
 
 const char* mgx_ctx_last_relax_kernel(const mgx_ctx* ctx) { return ctx ? ctx->last_relax_kernel : ""; }
+const char* mgx_ctx_last_rr_kernel(const mgx_ctx* ctx) { return ctx ? ctx->last_rr_kernel : ""; }
 
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     MGX_REQUIRE(ctx && name, MGX_ERR_INVALID, "set_param: NULL argument");
@@ -3022,6 +3039,18 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         ctx->cyc2_tail_points = value;
     } else if (!strcmp(name, "relax3d.fused")) {
         ctx->sweep_fused = value ? 1 : 0;  // levels of 513-point rows: one launch per red+black sweep (mgx_sweep3d.hip) or one per colour
+    } else if (!strcmp(name, "rr3d.black")) {
+        MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "set_param: rr3d.black = %d not in {0, 1, 2}", value);
+        ctx->rr_black = value;
+    } else if (!strcmp(name, "rr3d.black_waves")) {
+        MGX_REQUIRE(value == 0 || value == 12 || value == 16, MGX_ERR_INVALID, "set_param: rr3d.black_waves = %d not in {0, 12, 16}", value);
+        ctx->rr_black_waves = value;
+    } else if (!strcmp(name, "rr3d.black_abl")) {
+#ifdef MGX_DIAGNOSTICS
+        ctx->rr_black_abl = value;  // ablation bits of relax_rr3d_xs_kernel: WRONG results
+#else
+        return mgx::fail(MGX_ERR_INVALID, "set_param: 'rr3d.black_abl' exists only in diagnostic builds (make diag)");
+#endif
     } else if (!strcmp(name, "relax3d.fused_ilv")) {
         ctx->sweep_ilv = value ? 1 : 0;  // sweep3d_xs_kernel: memory instructions in groups between the rows of the arithmetic (1) or all first (0)
     } else if (!strcmp(name, "relax3d.fused_mid")) {

@@ -143,4 +143,42 @@ __device__ __forceinline__ real interpolate3d_point(int ox, int oy, int oz, Get 
                          get(1, 1, 1) + get(1, 1, 0));                                // DDD :302-329
 }
 
+// ------------------------------------------------------------------ device helpers shared by the kernel files
+// block -> tile of a 1-D launch over gx x gy x gz tiles (x fastest).  xcd_mode 1: consecutive blocks go to the eight XCDs
+// in turn, so every XCD is given one contiguous run of the tile order -- workgroups whose tiles share rows or cache lines
+// then share an L2 (see relax3d_xs_kernel); xcd_mode 0: plain order.
+__device__ __forceinline__ void tile_of_block(int xcd_mode, int gx, int gy, int& bx, int& by, int& bz) {
+    unsigned b = blockIdx.x;
+    if (xcd_mode == 1) {
+        const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
+        b = k * per + (k < rem ? k : rem) + (b >> 3);
+    }
+    bx = b % gx;
+    by = (b / gx) % gy;
+    bz = b / (gx * gy);
+}
+
+template <class real>
+__device__ __forceinline__ real wave_from_prev_lane(real x) {  // lane i gets lane i-1 (lane 0 keeps its own)
+    if constexpr (sizeof(real) == 8) {
+        int lo = __double2loint(x), hi = __double2hiint(x);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xf, 0xf, false));
+    }
+}
+template <class real>
+__device__ __forceinline__ real wave_from_next_lane(real x) {  // lane i gets lane i+1 (lane 63 keeps its own)
+    if constexpr (sizeof(real) == 8) {
+        int lo = __double2loint(x), hi = __double2hiint(x);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130, 0xf, 0xf, false));
+    }
+}
+
 }  // namespace mgx

@@ -84,6 +84,10 @@ class Context:
     def last_relax_kernel(self):
         return lib.mgx_ctx_last_relax_kernel(self._h).decode()
 
+    def last_rr_kernel(self):
+        """the fused black pass + residual + restrict kernel of the most recent smooth_residual_restrict call ("" = not fused)"""
+        return lib.mgx_ctx_last_rr_kernel(self._h).decode()
+
     def set_param(self, name, value):
         check(lib.mgx_ctx_set_param(self._h, name.encode(), C.c_int(int(value))))
 
@@ -339,6 +343,26 @@ class _Ops3D(_Ops):
         h = _rp(grid_spacing(n, rng, dtype), ct)
         return self._run(ctx, [v, f], lambda a, b: fn(ctx._h, a, b, _ip(n), h, C.c_int(ncycles), C.c_int(int(rim_is_zero))), 0, _shape(n),
                          dtype)
+
+    def smooth_residual_restrict(self, ctx, v, f, n, rng, ncycles, from_zero=False, v_rim_is_zero=False, mode=REF_COMPAT, dtype=None):
+        """x-split only: (v_out, coarse_f) of Relax(ncycles) + CalculateResidual + Restrict in one call
+        (mgx3dxs_smooth_residual_restrict: the last black pass inside the residual+restrict launch where the level takes it)"""
+        dtype = dtype or v.dtype
+        fn, ct = self._fn("smooth_residual_restrict", dtype)
+        h = _rp(grid_spacing(n, rng, dtype), ct)
+        cn = coarse_size(n)
+        pv, pf = ctx.to_device(xs_pack(np.ascontiguousarray(v, dtype))), ctx.to_device(xs_pack(np.ascontiguousarray(f, dtype)))
+        pc = ctx.to_device(xs_pack(np.full(_shape(cn), np.nan, dtype)))  # the call has to zero the coarse boundary itself
+        try:
+            check(fn(ctx._h, pv, pf, _ip(n), h, C.c_int(ncycles), C.c_int(int(from_zero)), C.c_int(int(v_rim_is_zero)), C.c_int(mode), pc,
+                     _ip(cn), C.c_int(0)))
+            isz = np.dtype(dtype).itemsize
+            out_v = xs_unpack(ctx.to_host(pv, tuple(_shape(n)[:-1]) + (xs_geometry(n[0], isz)[1],), dtype), n[0])
+            out_c = xs_unpack(ctx.to_host(pc, tuple(_shape(cn)[:-1]) + (xs_geometry(cn[0], isz)[1],), dtype), cn[0])
+            return out_v, out_c
+        finally:
+            for q in (pv, pf, pc):
+                ctx.free(q)
 
     def interpolate_correct_relax(self, ctx, v, f, n, rng, coarse, ncycles, dtype=None):
         """x-split only: v += Interpolate(coarse) on the interior, then ncycles >= 1 red-black sweeps, in one call"""
