@@ -2330,7 +2330,7 @@ int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[
     return MGX_OK;
 }
 
-bool relax_rr3d_xs_takes(const mgx_ctx* ctx, const int n[3], const int cn[3]);  // mgx_relax_rr3d.hip
+bool relax_rr3d_xs_takes(const mgx_ctx* ctx, const int n[3], const int cn[3], size_t elem);  // mgx_relax_rr3d.hip
 template <class real>
 bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int mode, bool rcp,
                           real* coarse_f, const int cn[3]);
@@ -2351,7 +2351,7 @@ int smooth_residual_restrict3d_xs(mgx_ctx* ctx, real* v, const real* f, const in
     MGX_REQUIRE(mode == MGX_RESIDUAL_REF_COMPAT || mode == MGX_RESIDUAL_CORRECT, MGX_ERR_INVALID,
                 "smooth_residual_restrict3d: bad mode %d", mode);
     ctx->last_rr_kernel[0] = 0;
-    if (ncycles < 1 || !relax_rr3d_xs_takes(ctx, n, cn)) {
+    if (ncycles < 1 || !relax_rr3d_xs_takes(ctx, n, cn, sizeof(real))) {
         st = from_zero ? relax3d_from_zero<real, XSplit>(ctx, v, f, n, h, ncycles, v_rim_is_zero) : relax3d<real, XSplit>(ctx, v, f, n, h, ncycles);
         if (st) return st;
         return residual_restrict3d<real, XSplit>(ctx, v, f, n, h, mode, coarse_f, cn, coarse_rim_is_zero != 0);

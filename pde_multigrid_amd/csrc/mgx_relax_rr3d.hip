@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(64 * TYW)
         const auto rv = plane_rsrc<real>(pv, PL, 4), rf = plane_rsrc<real>(pf, PL, 3), ro = plane_rsrc<real>(po, PL, 1);
         // ---- the black values of plane g (relaxed in the previous iteration) go out first: like the loads they have the whole
         // iteration before the wait at its end (stored right where they are computed, that wait stood for their round trip)
+        __builtin_amdgcn_s_setprio(3);  // requests leave the CU before the other waves' arithmetic (as in relax3d_xs_pipe_kernel)
         if (g >= max(g0, 1) && g <= pstore1 && strow && !(A & 2)) {
 #pragma unroll
             for (int o = 0; o < 2; o++) {
@@ -185,6 +186,7 @@ __global__ void __launch_bounds__(64 * TYW)
                 fX[o][hr] = buf_load<real>(rf, off[hr], roff[o] + 2 * PL);
             if (o == 1 && bot && moreK) fX[1][1 - hr] = buf_load<real>(rv, off[hr], roffD + 2 * PL);  // the row below, red there
         }
+        __builtin_amdgcn_s_setprio(0);
         // ---- the coarse plane whose own share was formed in the previous iteration
         if (PAR == 0 && g >= g0 + 3 && !(A & 32)) complete((g - 2) >> 1);
         // ---- black points of plane g + 1
@@ -293,15 +295,18 @@ __global__ void __launch_bounds__(64 * TYW)
 
 // One launch: black pass + residual + restrict over the whole level.  hx2 .. : squared spacings; rcp: the residual multiplies by
 // their exact reciprocals.  Returns false when the level is not taken (too small for the tile shape).
-bool relax_rr3d_xs_takes(const mgx_ctx* ctx, const int n[3], const int cn[3]) {
+// Automatic choice (measured, tools/rr_black_time.py): fp64 from 513-point rows on (513^3: 0.55 against 0.71 ms for the black
+// pass + residual + restrict, 1025^3: 11.5 against 13.6 ms with the two red+black sweeps before; 257^3: equal, left alone);
+// fp32 moves half the bytes with the same instructions and is no faster than its separate launches (513^3: 0.91 / 0.87 ms).
+bool relax_rr3d_xs_takes(const mgx_ctx* ctx, const int n[3], const int cn[3], size_t elem) {
     if (!ctx->rr_black || cn[0] < 3 || cn[1] < 3 || cn[2] < 3) return false;
-    return ctx->rr_black == 2 || (n[0] >= 257 && n[1] >= 129 && n[2] >= 65);
+    return ctx->rr_black == 2 || (elem == 8 && n[0] >= 385 && n[1] >= 129 && n[2] >= 65);
 }
 
 template <class real>
 bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int mode, bool rcp,
                           real* coarse_f, const int cn[3]) {
-    if (!relax_rr3d_xs_takes(ctx, n, cn)) return false;
+    if (!relax_rr3d_xs_takes(ctx, n, cn, sizeof(real))) return false;
     const int T = ctx->rr_black_waves == 12 ? 12 : 16;
     const int gx = ceil_div(cn[0] - 2, 61), gy = ceil_div(cn[1] - 2, T - 2);
     const int tiles = gx * gy, planes = cn[2] - 2;

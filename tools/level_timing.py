@@ -54,5 +54,12 @@ n0, n1 = (C.c_int * 3)(*g0.sizeXYZ), (C.c_int * 3)(*g1.sizeXYZ)
 rr = getattr(P.lib, "mgx3dxs_residual_restrict_keep_rim_" + sfx)
 ic = getattr(P.lib, "mgx3dxs_interpolate_correct_colour_" + sfx)
 print("  residual+restrict               %.4f ms" % timed(lambda: P.check(rr(ctx._h, C.c_void_p(g0.d_v), C.c_void_p(g0.d_f), n0, h, C.c_int(0), C.c_void_p(g1.d_f), n1))))
+srr = getattr(P.lib, "mgx3dxs_smooth_residual_restrict_" + sfx)
+icr = getattr(P.lib, "mgx3dxs_interpolate_correct_relax_" + sfx)
+print("  the way down in one call: Relax(2) + residual + restrict   %.4f ms  [%s]" % (
+    timed(lambda: P.check(srr(ctx._h, C.c_void_p(g0.d_v), C.c_void_p(g0.d_f), n0, h, C.c_int(2), C.c_int(0), C.c_int(0), C.c_int(0),
+                              C.c_void_p(g1.d_f), n1, C.c_int(1)))), ctx.last_rr_kernel() or "separate launches"))
+print("  the way up in one call: interpolate + correct + Relax(2)   %.4f ms" % timed(
+    lambda: P.check(icr(ctx._h, C.c_void_p(g0.d_v), C.c_void_p(g0.d_f), n0, h, C.c_void_p(g1.d_v), n1, C.c_int(2)))))
 print("  interpolate+correct (black)     %.4f ms" % timed(lambda: P.check(ic(ctx._h, C.c_void_p(g0.d_v), n0, C.c_void_p(g1.d_v), n1, C.c_int(1)))))
 print("  zero fill of the coarse v       %.4f ms" % timed(lambda: mg.setToValue_v(1, 0.0, True)))
