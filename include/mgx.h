@@ -320,6 +320,16 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
                                                const real h[3], int ncycles, int from_zero,             \
                                                int v_rim_is_zero, int mode, real* coarse_f,             \
                                                const int cn[3], int coarse_rim_is_zero);                \
+    /* relax_rr_slab: that fused launch alone, on a z-slab (or the whole grid): the BLACK pass of the      */ \
+    /* GLOBAL fine planes [2 pzbeg - 1, 2 pzend - 1] + residual + restrict into the GLOBAL coarse planes   */ \
+    /* [pzbeg, pzend).  n / cn are global sizes, v / f start at global plane fzoff (even), coarse_f at     */ \
+    /* global coarse plane czoff.  It reads only red values of v (fine planes 2 pzbeg - 3 ... 2 pzend + 1, */ \
+    /* clipped to the grid: they must be present and current) and f.  relax_rr_takes: 1 when a level of   */ \
+    /* these global sizes has the kernel; otherwise relax_rr_slab fails with MGX_ERR_INVALID.              */ \
+    int mgx3dxs_relax_rr_takes_##SFX(const mgx_ctx* ctx, const int n[3], const int cn[3]);              \
+    int mgx3dxs_relax_rr_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], int fzoff,    \
+                                    const real h[3], int mode, real* coarse_f, const int cn[3],         \
+                                    int czoff, int pzbeg, int pzend);                                   \
     /* The same on a z-slab (the post-smoothing of the slab-decomposed cycle), in its two pieces.  n / cn */ \
     /* are GLOBAL sizes, v / f start at global plane fzoff (even), coarse_v at global plane czoff and     */ \
     /* holds cplanes planes.  corr_fused_takes: 1 when a level with these rows and `nplanes` planes to    */ \

@@ -2333,7 +2333,35 @@ int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[
 bool relax_rr3d_xs_takes(const mgx_ctx* ctx, const int n[3], const int cn[3], size_t elem);  // mgx_relax_rr3d.hip
 template <class real>
 bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int mode, bool rcp,
-                          real* coarse_f, const int cn[3]);
+                          real* coarse_f, const int cn[3], int fzoff, int czoff, int pzbeg, int pzend);
+
+// The fused launch alone on a z-slab (or the whole grid): black pass of the GLOBAL fine planes [2 pzbeg - 1, 2 pzend - 1] +
+// residual + restrict into the GLOBAL coarse planes [pzbeg, pzend).  n / cn global sizes, v / f start at global plane fzoff,
+// coarse_f at global coarse plane czoff.  Reads the red values of the fine planes [2 pzbeg - 3, 2 pzend + 1] (clipped to the
+// grid) and f; the coarse planes are zeroed first (boundary entries stay 0).
+template <class real>
+int relax_rr3d_slab(mgx_ctx* ctx, real* v, const real* f, const int n[3], int fzoff, const real h[3], int mode, real* coarse_f,
+                    const int cn[3], int czoff, int pzbeg, int pzend) {
+    MGX_REQUIRE(ctx && v && f && h && coarse_f, MGX_ERR_INVALID, "relax_rr_slab: NULL argument");
+    MGX_USE(ctx);
+    int st = check_n3(n, "relax_rr_slab");
+    if (st) return st;
+    st = check_coarse3(n, cn, "relax_rr_slab");
+    if (st) return st;
+    MGX_REQUIRE(mode == MGX_RESIDUAL_REF_COMPAT || mode == MGX_RESIDUAL_CORRECT, MGX_ERR_INVALID, "relax_rr_slab: bad mode %d", mode);
+    MGX_REQUIRE(pzbeg >= 1 && pzend <= cn[2] - 1 && pzbeg < pzend && czoff >= 0 && czoff <= pzbeg && fzoff >= 0 && (fzoff & 1) == 0 &&
+                    fzoff <= (2 * pzbeg - 3 > 0 ? 2 * pzbeg - 3 : 0),
+                MGX_ERR_INVALID, "relax_rr_slab: coarse planes [%d, %d) with offsets %d / %d", pzbeg, pzend, fzoff, czoff);
+    MGX_REQUIRE(relax_rr3d_xs_takes(ctx, n, cn, sizeof(real)), MGX_ERR_INVALID, "relax_rr_slab: the level is not taken (ask relax_rr_takes)");
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    const Geo<XSplit, real> gc(cn[0], cn[1]);
+    MGX_TRY_RET(fill_zero(ctx, coarse_f + gc.PL * (size_t)(pzbeg - czoff), gc.PL * (size_t)(pzend - pzbeg) * sizeof(real)));
+    const bool rcp = ctx->rr_rcp && exact_reciprocal(hx2) && exact_reciprocal(hy2) && exact_reciprocal(hz2);
+    MGX_REQUIRE(relax_rr3d_xs_launch<real>(ctx, v, f, n, hx2, hy2, hz2, mode, rcp, coarse_f, cn, fzoff, czoff, pzbeg, pzend), MGX_ERR_INVALID,
+                "relax_rr_slab: launch refused");
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
 
 // The way down on one level: Relax(ncycles) (from_zero: on v = 0, as relax3d_from_zero), CalculateResidual, Restrict
 // (N3/MultiGrid3D.cpp:626-632).  Where the level takes it the last black pass runs inside the residual+restrict launch
@@ -2370,7 +2398,7 @@ int smooth_residual_restrict3d_xs(mgx_ctx* ctx, real* v, const real* f, const in
     for (; s < 2 * ncycles - 1; s++) relax3d_xs_pass<real>(ctx, v, f, n[0], n[1], 1, n[2] - 1, hx2, hy2, hz2, s & 1);
     if (!coarse_rim_is_zero) MGX_TRY_RET(fill_zero(ctx, coarse_f, Geo<XSplit, real>(cn[0], cn[1]).PL * (size_t)cn[2] * sizeof(real)));
     const bool rcp = ctx->rr_rcp && exact_reciprocal(hx2) && exact_reciprocal(hy2) && exact_reciprocal(hz2);
-    MGX_REQUIRE(relax_rr3d_xs_launch<real>(ctx, v, f, n, hx2, hy2, hz2, mode, rcp, coarse_f, cn), MGX_ERR_INVALID,
+    MGX_REQUIRE(relax_rr3d_xs_launch<real>(ctx, v, f, n, hx2, hy2, hz2, mode, rcp, coarse_f, cn, 0, 0, 1, cn[2] - 1), MGX_ERR_INVALID,
                 "smooth_residual_restrict3d: the fused launch refused a level it had accepted");
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2926,6 +2954,14 @@ template int relax3d_xs_from_zero<double>(mgx_ctx*, double*, const double*, cons
                                                int coarse_rim_is_zero) {                                         \
         return mgx::smooth_residual_restrict3d_xs<real>(ctx, v, f, n, h, ncycles, from_zero, v_rim_is_zero, mode, \
                                                         coarse_f, cn, coarse_rim_is_zero);                       \
+    }                                                                                                            \
+    int mgx3dxs_relax_rr_takes_##SFX(const mgx_ctx* ctx, const int n[3], const int cn[3]) {                     \
+        return ctx && n && cn && mgx::relax_rr3d_xs_takes(ctx, n, cn, sizeof(real));                             \
+    }                                                                                                            \
+    int mgx3dxs_relax_rr_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, const int n[3], int fzoff,            \
+                                    const real h[3], int mode, real* coarse_f, const int cn[3], int czoff,       \
+                                    int pzbeg, int pzend) {                                                      \
+        return mgx::relax_rr3d_slab<real>(ctx, v, f, n, fzoff, h, mode, coarse_f, cn, czoff, pzbeg, pzend);      \
     }                                                                                                            \
     int mgx3dxs_corr_fused_takes_##SFX(const mgx_ctx* ctx, const int n[3], int nplanes) {                        \
         return ctx && n && mgx::corr_fused_takes(ctx, n[0], n[1], n[2], nplanes);                                \

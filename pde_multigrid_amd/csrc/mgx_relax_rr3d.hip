@@ -62,7 +62,7 @@ template <class real, int MODE, int TYW, int DBG = 0>
 __global__ void __launch_bounds__(64 * TYW)
     relax_rr3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy, int sz,
                          real hx2, real hy2, real hz2, real qx, real qy, real qz, real* __restrict__ coarse, int cx, int cy, int cz,
-                         int pzchunk, int gx, int gy, int xcd_mode, int abl = 0) {
+                         int pzchunk, int gx, int gy, int xcd_mode, int pzbeg, int pzend, int fzoff, int czoff, int abl = 0) {
     const int A = DBG ? abl : 0;
     constexpr int NPW = TYW - 2;  // producing waves = coarse rows of a tile
     __shared__ real eR[3][TYW][2][64];  // [plane % 3][wave][first / last row][lane]: red half
@@ -73,11 +73,16 @@ __global__ void __launch_bounds__(64 * TYW)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
     int bx, by, bz;
     tile_of_block(xcd_mode, gx, gy, bx, by, bz);
-    const int pz0 = 1 + bz * pzchunk, pz1 = min(pz0 + pzchunk, cz - 1);
+    // the GLOBAL coarse planes [pzbeg, pzend) in runs of pzchunk; v / f start at global fine plane fzoff, coarse at global
+    // coarse plane czoff (a z-slab; the whole grid: 1, cz - 1, 0, 0).  sz, cz and every plane index below are global.
+    const int pz0 = pzbeg + bz * pzchunk, pz1 = min(pz0 + pzchunk, pzend);
     if (pz0 >= pz1) return;  // uniform over the workgroup
+    vin -= (ptrdiff_t)fzoff * (ptrdiff_t)gf.PL;  // index by global plane from here on (never dereferenced outside the slab)
+    vout -= (ptrdiff_t)fzoff * (ptrdiff_t)gf.PL;
+    f -= (ptrdiff_t)fzoff * (ptrdiff_t)gf.PL;
     const int g0 = 2 * pz0 - 1, glast = 2 * pz1 - 1;
     const int rmax = min(glast + 2, sz - 1), fmax = min(glast + 1, sz - 2), kmax = min(glast + 1, sz - 1);
-    const int pstore1 = glast < sz - 2 ? glast - 1 : glast;  // black planes [g0, pstore1] are stored by this run
+    const int pstore1 = pz1 < pzend ? glast - 1 : glast;  // black planes [g0, pstore1] are stored by this run (glast by the next, if any)
 
     const bool top = w == 0, bot = w == TYW - 1, prod = !top && !bot;
     const int cyb = by * NPW + w;  // coarse row of the wave (the halo waves: the neighbouring tiles' rows)
@@ -126,9 +131,9 @@ __global__ void __launch_bounds__(64 * TYW)
     // ---- set-up for the first iteration gs = g0 - 2 (odd; its black half of row o is o)
     const int gs = g0 - 2;
     {
-        const auto q0 = plane_rsrc<real>(vin + (size_t)max(gs, 0) * gf.PL, PL, 1);
-        const auto q1 = plane_rsrc<real>(vin + (size_t)(gs + 1) * gf.PL, PL, 2);
-        const auto qf = plane_rsrc<real>(f + (size_t)(gs + 1) * gf.PL, PL, 1);
+        const auto q0 = plane_rsrc<real>(vin + (ptrdiff_t)max(gs, 0) * (ptrdiff_t)gf.PL, PL, 1);
+        const auto q1 = plane_rsrc<real>(vin + (ptrdiff_t)(gs + 1) * (ptrdiff_t)gf.PL, PL, 2);
+        const auto qf = plane_rsrc<real>(f + (ptrdiff_t)(gs + 1) * (ptrdiff_t)gf.PL, PL, 1);
 #pragma unroll
         for (int o = 0; o < 2; o++) {
             vC[o][o] = buf_load<real>(q0, off[o], roff[o]);
@@ -155,7 +160,7 @@ __global__ void __launch_bounds__(64 * TYW)
     auto complete = [&](int pz) __attribute__((always_inline)) {
         const real ea = pS[wD][0][lane], eb = pS[wD][1][lane], ec = pS[wD][2][lane];
         if (produces)
-            coarse[gc.row(cyb, pz) + gc.pos(i)] =
+            coarse[gc.row(cyb, pz - czoff) + gc.pos(i)] =
                 k1 + (1 / 16.0f) * (k2 + (k3 + ea)) + (1 / 32.0f) * (k4 + eb) + (1 / 64.0f) * (k5 + ec);
     };
 
@@ -305,11 +310,13 @@ bool relax_rr3d_xs_takes(const mgx_ctx* ctx, const int n[3], const int cn[3], si
 
 template <class real>
 bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int mode, bool rcp,
-                          real* coarse_f, const int cn[3]) {
-    if (!relax_rr3d_xs_takes(ctx, n, cn, sizeof(real))) return false;
+                          real* coarse_f, const int cn[3], int fzoff, int czoff, int pzbeg, int pzend) {
+    // n, cn: GLOBAL sizes; v / f start at global fine plane fzoff, coarse_f at global coarse plane czoff; the launch relaxes
+    // the black points of the fine planes [2 pzbeg - 1, 2 pzend - 1] and forms the coarse planes [pzbeg, pzend)
+    if (!relax_rr3d_xs_takes(ctx, n, cn, sizeof(real)) || pzbeg < 1 || pzend > cn[2] - 1 || pzend <= pzbeg) return false;
     const int T = ctx->rr_black_waves == 12 ? 12 : 16;
     const int gx = ceil_div(cn[0] - 2, 61), gy = ceil_div(cn[1] - 2, T - 2);
-    const int tiles = gx * gy, planes = cn[2] - 2;
+    const int tiles = gx * gy, planes = pzend - pzbeg;
     int pzc = ctx->rr_pzchunk;
     if (pzc <= 0) {
         // all workgroups take the same time and one fits a CU: the fewest runs that fill whole rounds to 90 %, runs of at least
@@ -333,7 +340,8 @@ bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], 
     }
 #define MGX_BRR_D(M, W, D)                                                                                                     \
     hipLaunchKernelGGL((relax_rr3d_xs_kernel<real, M, W, D>), g, dim3(64, W, 1), 0, ctx->compute, (const real*)v, v, f, n[0], n[1], \
-                       n[2], hx2, hy2, hz2, qx, qy, qz, coarse_f, cn[0], cn[1], cn[2], pzc, gx, gy, ctx->rr_xcd >= 1, ctx->rr_black_abl)
+                       n[2], hx2, hy2, hz2, qx, qy, qz, coarse_f, cn[0], cn[1], cn[2], pzc, gx, gy, ctx->rr_xcd >= 1, pzbeg, pzend, fzoff,   \
+                       czoff, ctx->rr_black_abl)
 #ifdef MGX_DIAGNOSTICS
 #define MGX_BRR(M, W) do { if (ctx->rr_black_abl) MGX_BRR_D(M, W, 1); else MGX_BRR_D(M, W, 0); } while (0)
 #else
@@ -355,8 +363,9 @@ bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], 
              (mode == MGX_RESIDUAL_REF_COMPAT ? 0 : 1) + (rcp ? 2 : 0), T);
     return true;
 }
-template bool relax_rr3d_xs_launch<float>(mgx_ctx*, float*, const float*, const int[3], float, float, float, int, bool, float*, const int[3]);
+template bool relax_rr3d_xs_launch<float>(mgx_ctx*, float*, const float*, const int[3], float, float, float, int, bool, float*, const int[3],
+                                          int, int, int, int);
 template bool relax_rr3d_xs_launch<double>(mgx_ctx*, double*, const double*, const int[3], double, double, double, int, bool, double*,
-                                           const int[3]);
+                                           const int[3], int, int, int, int);
 
 }  // namespace mgx

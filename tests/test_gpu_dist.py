@@ -23,10 +23,13 @@ DELAY_US = 300  # a colour pass of these grids takes 5-50 us: every transfer arr
 
 
 def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COMPAT, v0=None, f0=None, nlevels=0, fmg=0,
-              delay_us=DELAY_US, drop_waits=False, extra=None, join_timeout=100, inline_bytes=0, v_levels=None):
+              delay_us=DELAY_US, drop_waits=False, extra=None, join_timeout=100, inline_bytes=0, v_levels=None, params=None):
     """inline_bytes = 0: every level runs the OVERLAPPED schedule (comm stream, edge planes first) -- what these tests were
     written for; None: the library default (small levels exchange inline on the compute stream); a number: that threshold"""
     ctxs = [P.Context(0) for _ in range(nranks)]
+    for c in ctxs:
+        for k, val in (params or {}).items():
+            c.set_param(k, val)
     group = P.LocalGroup(nranks)
     group.set_test_hooks(delay_us, drop_waits)
     for r, c in enumerate(ctxs):
@@ -143,6 +146,28 @@ def test_dist_correction_read_on_the_fly_on_slabs(nranks, inline_bytes, v2):
     got, info = run_ranks(nranks, n3, rg, np.float64, 2, v2, 2, 16, v0=v0, f0=f0, inline_bytes=inline_bytes,
                           extra=lambda mg: names.setdefault(mg.rank, mg.ctx.last_relax_kernel()))
     want = O.cycle3d(n3, rg, mode=0, v1=2, v2=v2, reps=2, v=v0, f=f0, dtype=np.float64)
+    assert bits_equal(got, want)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("nranks,v1,dtype", [(1, 2, np.float64), (2, 1, np.float64), (2, 2, np.float32), (4, 2, np.float64), (8, 1, np.float64),
+                                             (8, 3, np.float32)])
+def test_dist_last_black_pass_inside_residual_restrict_on_slabs(nranks, v1, dtype):
+    """the way down of a distributed level with the last black pass inside the residual+restrict launch
+    (mgx3dxs_relax_rr_slab on the coarse planes whose inputs are local, edge planes by the colour-pass kernel before the
+    exchanges, the one or two remaining coarse planes after them): "rr3d.black" = 2 makes these small levels take it.  Two
+    cycles from random data (the second one starts from non-trivial v on every level), coarse level distributed (1, 2, 4
+    ranks: from-zero pre-smoothing on it) or replicated (8 ranks: the all-gathered share), against the oracle."""
+    n3 = [129, 65, 129]
+    rng = np.random.default_rng(300 + nranks + v1)
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    v0 = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    f0 = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    names = {}
+    got, info = run_ranks(nranks, n3, rg, dtype, v1, 2, 2, 16, v0=v0, f0=f0, params={"rr3d.black": 2},
+                          extra=lambda mg: names.setdefault(mg.rank, mg.ctx.last_rr_kernel()))
+    assert all(names[r].startswith("relax_rr3d_xs_kernel") for r in range(nranks)), names
+    want = O.cycle3d(n3, rg, mode=0, v1=v1, v2=2, reps=2, v=v0, f=f0, dtype=dtype)
     assert bits_equal(got, want)
 
 

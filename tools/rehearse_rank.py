@@ -3,7 +3,8 @@
 (mgx_comm_init_rehearsal): its own 128-plane slab hierarchy, the real overlap schedule, every ghost plane, all-gather and
 all-reduce at full size -- through RCCL, from this rank to itself.  The values received are wrong, so no result is checked;
 what is measured is this rank's compute plus the launch / stream / RCCL call pattern, i.e. everything but the wire.
-    python tools/rehearse_rank.py [n=1025] [nranks=8] [one_gpu_ms=0]"""
+    python tools/rehearse_rank.py [n=1025] [nranks=8] [one_gpu_ms=0] [only_rank=-1]
+only_rank >= 0: that rank alone with the library's default exchange modes (for a profiler; give one_gpu_ms > 0 to skip the reference run)"""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ import pde_multigrid_amd as P  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1025
 nranks = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 one_gpu_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+only_rank = int(sys.argv[4]) if len(sys.argv) > 4 else -1
 R3 = [0, 1, 0, 1, 0, 1]
 
 
@@ -41,8 +43,9 @@ if one_gpu_ms <= 0:
     ctx.close()
 print("one GPU, the whole %d^3 hierarchy: %.3f ms per V(2,2) cycle -> perfect %d-way share %.3f ms" % (n, one_gpu_ms, nranks, one_gpu_ms / nranks))
 rows = []
-for inline_bytes, label in ((None, "library default (inline_bytes = 96 MB)"), (0, "every level overlapped"), (1 << 40, "every level inline")):
-    for vr in (0, nranks // 2, nranks - 1):
+modes = ((None, "library default (inline_bytes = 96 MB)"), (0, "every level overlapped"), (1 << 40, "every level inline"))
+for inline_bytes, label in (modes[:1] if only_rank >= 0 else modes):
+    for vr in ((only_rank,) if only_rank >= 0 else (0, nranks // 2, nranks - 1)):
         ctx = P.Context(0)
         ctx.comm_init_rehearsal(P.Context.unique_id(), vr, nranks)
         mg = P.DistMultiGrid3D(ctx, [n] * 3, R3, np.float64, min_planes=32, inline_bytes=inline_bytes)
