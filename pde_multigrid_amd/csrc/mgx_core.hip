@@ -120,6 +120,7 @@ int mgx_ctx_destroy(mgx_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->rehearse_buf) (void)hipFree(ctx->rehearse_buf);
     if (ctx->sweep_dev) (void)hipFree(ctx->sweep_dev);
+    if (ctx->resident_buf) (void)hipFree(ctx->resident_buf);
     if (ctx->sweep_abort) (void)hipHostFree(ctx->sweep_abort);
     (void)hipEventDestroy(ctx->ev_compute);
     (void)hipEventDestroy(ctx->ev_comm);

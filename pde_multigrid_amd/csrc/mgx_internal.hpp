@@ -44,6 +44,11 @@ struct mgx_ctx {
     int sweep_fused = 0;   // 1: one launch per red+black sweep where the level takes it (mgx_sweep3d.hip); 0 = one per colour (default
                            // while the one-launch kernel measures slower: DESIGN.md section 5)
     int sweep_mid = 1;     // cache-resident levels (33 ... 129 points per row): one launch per red+black sweep (sweep3d_xs_mid_kernel)
+    int relax_resident = 1;      // cache-resident levels: all passes of a Relax call in one launch (mgx_resident3d.hip) ...
+    int relax_resident_min = 3;  // ... from this many sweeps per call on
+    void* resident_buf = nullptr;  // its exchange buffer (tagged face lines)
+    size_t resident_bytes = 0;
+    unsigned resident_launches = 0;
     int sweep_ilv = 0;     // that kernel with its memory instructions interleaved with the arithmetic instead of issued first
     int sweep_lead = 0;    // planes the red stage of that kernel runs ahead of the black stage (0 = default)
     int sweep_dbg = 0;     // diagnostic builds: 1 = cycle stamps, + 2 * ablation bits (sweep3d_xs_kernel)

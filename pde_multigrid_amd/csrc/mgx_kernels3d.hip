@@ -39,6 +39,7 @@
 //   relayout3d_kernel         Natural <-> XSplit (upload / download of the hierarchy)
 #include "mgx_internal.hpp"
 #include "mgx_kernels3d.hpp"
+#include "mgx_sync.hpp"
 
 namespace mgx {
 
@@ -2036,7 +2037,8 @@ int relax3d(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3
         MGX_LAUNCH_CHECK();
         return MGX_OK;
     }
-    if (L::xsplit) st = relax3d_xsplit<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles);
+    if (L::xsplit && ncycles > 0 && relax3d_resident_takes(ctx, n, ncycles)) st = relax3d_resident<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles, 0);
+    else if (L::xsplit) st = relax3d_xsplit<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles);
     else st = relax3d_natural<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles);
     if (st) return st;
     MGX_LAUNCH_CHECK();
@@ -2061,6 +2063,12 @@ int relax3d_from_zero(mgx_ctx* ctx, real* v, const real* f, const int n[3], cons
         return relax3d<real, L>(ctx, v, f, n, h, ncycles);
     }
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // :498-500
+    if (L::xsplit && relax3d_resident_takes(ctx, n, ncycles)) {  // all passes in one launch, the tile starts as zeros
+        st = relax3d_resident<real>(ctx, v, f, n, hx2, hy2, hz2, ncycles, 1);
+        if (st) return st;
+        MGX_LAUNCH_CHECK();
+        return MGX_OK;
+    }
     hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, L>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
                        ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0, 1);
     for (int s = 1; s < 2 * ncycles; s++) {
@@ -3075,6 +3083,12 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         ctx->cyc2_tail_points = value;
     } else if (!strcmp(name, "relax3d.fused")) {
         ctx->sweep_fused = value ? 1 : 0;  // levels of 513-point rows: one launch per red+black sweep (mgx_sweep3d.hip) or one per colour
+    } else if (!strcmp(name, "relax3d.resident")) {
+        MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: relax3d.resident = %d not in {0, 1}", value);
+        ctx->relax_resident = value;
+    } else if (!strcmp(name, "relax3d.resident_min")) {
+        MGX_REQUIRE(value >= 1, MGX_ERR_INVALID, "set_param: relax3d.resident_min = %d < 1", value);
+        ctx->relax_resident_min = value;
     } else if (!strcmp(name, "rr3d.black")) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "set_param: rr3d.black = %d not in {0, 1, 2}", value);
         ctx->rr_black = value;

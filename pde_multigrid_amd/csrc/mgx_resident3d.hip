@@ -1,0 +1,262 @@
+// mgx_resident3d.hip -- MultiGrid3D::Relax (N3/MultiGrid3D.cpp:489-567) on the cache-resident levels (33 ... 129 points per
+// row, x-split layout): ALL colour passes of a Relax call in ONE launch.
+//
+// On these levels a colour pass is a 5-8 us launch that moves almost nothing; a Relax call of the reference's own workloads
+// (FMG(2, 3000, 3000): 6000 passes per level visit) is nothing but launch latency.  Here the level is cut into tiles of
+// 8 rows x 8 planes x all of x, one workgroup per tile, all resident at once (at most one per CU: 129^3 = 16 x 16 tiles).  A
+// workgroup loads its tile once, keeps v in LDS (with a ring of halo lines around it) and f in registers, runs every pass on
+// it and writes the tile back at the end.  Between passes the tiles exchange the lines on their four faces through a small
+// buffer in memory.  Every value travels WITH ITS TAG -- (launch epoch, pass) next to the value in one naturally aligned
+// 8-byte (fp32) / 16-byte (fp64) element, stored and loaded by one lane in one write-through (sc1) access -- so there is no
+// progress word, no draining of stores and no second round trip: after pass p a wave stores the half-lines it has just
+// updated on the tile's faces; before pass p + 1 the wave in charge of a halo line loads the neighbour's element and repeats
+// until every lane sees the tag of pass p (bounded; a wait that does not end sets the context's abort word, mgx_sync.hpp).
+// A pass reads only the other colour, which the neighbours updated in the pass before, so one exchange per pass is all
+// there is; the buffer is double-buffered by pass parity (a neighbour may be one pass ahead, never two).  Every point is
+// computed from exactly the values the serial loops would use, with relax3d_point: bit-identical results.  One hand-off
+// costs ~2 us (the per-workgroup-flag form of the same kernel: ~4 us; a launch of a colour pass: 3.7-7 us).
+//
+// A wave owns 2 rows x 2 planes of the tile (16 waves); lane i the x-pair {2i, 2i+1}.  With 129 points per row the last even
+// entry (x = 128, a boundary value) has no lane: it rides in a register per line.
+#include "mgx_internal.hpp"
+#include "mgx_kernels3d.hpp"
+#include "mgx_sync.hpp"
+
+namespace mgx {
+
+constexpr int RT = 8;  // tile edge in rows and in planes
+
+// one exchanged element = {value, tag}: 2 x 32 bit (fp32) or 2 x 64 bit (fp64), accessed as ONE aligned 8- / 16-byte unit
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <class real>
+__device__ __forceinline__ void put_tagged(__amdgpu_buffer_rsrc_t r, unsigned elem, real x, u64 tag) {
+    if constexpr (sizeof(real) == 4) {
+        u32x2_t t;
+        t.x = __float_as_uint(x);
+        t.y = (unsigned)tag;
+        __builtin_amdgcn_raw_buffer_store_b64(t, r, elem * 8u, 0, 16);  // aux 16 = sc1: write-through, visible to the other XCDs
+    } else {
+        const u64 b = (u64)__double_as_longlong(x);
+        u32x4_t t;
+        t.x = (unsigned)b;
+        t.y = (unsigned)(b >> 32);
+        t.z = (unsigned)tag;
+        t.w = (unsigned)(tag >> 32);
+        __builtin_amdgcn_raw_buffer_store_b128(t, r, elem * 16u, 0, 16);
+    }
+}
+template <class real>
+__device__ __forceinline__ bool get_tagged(__amdgpu_buffer_rsrc_t r, unsigned elem, u64 tag, real* x) {
+    if constexpr (sizeof(real) == 4) {
+        const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, elem * 8u, 0, 16);
+        *x = __uint_as_float(t.x);
+        return t.y == (unsigned)tag;
+    } else {
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, elem * 16u, 0, 16);
+        *x = __longlong_as_double((long long)(((u64)t.y << 32) | (u64)t.x));
+        return (((u64)t.w << 32) | (u64)t.z) == tag;
+    }
+}
+template <class real>
+__device__ __forceinline__ u64 pass_tag(u64 ep, int p) {  // never 0 (a fresh buffer is zeroed); fp32: 13 bits of pass, 19 of epoch
+    return sizeof(real) == 4 ? (u64)(unsigned)((unsigned)ep * 8192u + (unsigned)p + 1u) : ((ep << 20) | (u64)(p + 1));
+}
+
+template <class real>
+__global__ void __launch_bounds__(1024)
+    relax3d_xs_resident_kernel(real* __restrict__ v, const real* __restrict__ f, int sx, int sy, int sz, real hx2, real hy2, real hz2,
+                               int npasses, int zero_start, int gy, int gz, void* __restrict__ xbuf, unsigned xbytes, SweepSync sync) {
+    __shared__ real L[RT + 2][RT + 2][2][64];  // [row slot][plane slot][half][pair]: slot 0 / RT + 1 = the halo ring
+    const Geo<XSplit, real> g(sx, sy);
+    const int lane = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int M = (sx + 1) >> 1;  // entries of the even half; the odd half has M - 1
+    const int ty = blockIdx.x % gy, tz = blockIdx.x / gy;
+    const int y0 = 1 + ty * RT, z0 = 1 + tz * RT;
+    const bool has_ym = ty > 0, has_yp = ty < gy - 1, has_zm = tz > 0, has_zp = tz < gz - 1;
+    const u64 ep = *sync.epoch;  // written by the previous launch's last workgroup: a kernel boundary lies in between
+    const double rd = relax3d_rd<real>(hx2, hy2, hz2);
+    const unsigned facesz = RT * 64, tilesz = 4 * facesz, bufsz = gridDim.x * tilesz;  // xbuf[2][tile][face][RT][64] elements
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, (int)xbytes, 0x00020000);
+
+    // ---- the tile and its halo ring from memory (corners are never read): all loads of a wave first, then LDS (one memory
+    // round trip for the wave's seven lines instead of seven)
+    {
+        constexpr int NL = ((RT + 2) * (RT + 2) + 15) / 16;
+        real ta[NL], tb[NL];
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int idx = w + 16 * j;
+            const int ly = idx / (RT + 2), lz = idx % (RT + 2);
+            const int y = y0 - 1 + ly, z = z0 - 1 + lz;
+            ta[j] = tb[j] = 0;
+            if (idx < (RT + 2) * (RT + 2) && y <= sy - 1 && z <= sz - 1) {
+                const bool inner = y >= 1 && y <= sy - 2 && z >= 1 && z <= sz - 2;
+                if (!(zero_start && inner)) {
+                    const real* row = v + g.row(y, z);
+                    if (lane < M) ta[j] = row[lane];
+                    if (lane < M - 1) tb[j] = row[g.H + lane];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int idx = w + 16 * j;
+            if (idx < (RT + 2) * (RT + 2)) {
+                L[idx / (RT + 2)][idx % (RT + 2)][0][lane] = ta[j];
+                L[idx / (RT + 2)][idx % (RT + 2)][1][lane] = tb[j];
+            }
+        }
+    }
+    // ---- own lines: f, the boundary entry past the last lane
+    int ly[4], lz[4], par[4];
+    bool valid[4];
+    real fA[4], fB[4], xR[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        const int ry = 2 * (w & 3) + (l & 1), rz = 2 * (w >> 2) + (l >> 1);
+        const int y = y0 + ry, z = z0 + rz;
+        ly[l] = ry + 1;
+        lz[l] = rz + 1;
+        par[l] = (y + z) & 1;
+        valid[l] = y <= sy - 2 && z <= sz - 2;
+        fA[l] = fB[l] = xR[l] = 0;
+        if (valid[l]) {
+            const size_t row = g.row(y, z);
+            if (lane < M) fA[l] = f[row + lane];
+            if (lane < M - 1) fB[l] = f[row + g.H + lane];
+            if (M - 1 == 64 && !zero_start) xR[l] = v[row + 64];
+        }
+    }
+    __syncthreads();
+
+    bool gave_up = false;
+    for (int p = 0; p < npasses; p++) {
+        const int c = p & 1;  // red = 0 first (N3/MultiGrid3D.cpp:515, :544)
+        if (p > 0) {
+            // ---- the neighbours' face lines of pass p - 1 into the halo ring: wave w takes face w >> 2, lines 2 (w & 3), + 1
+            const int face = w >> 2;
+            const bool have = face == 0 ? has_ym : (face == 1 ? has_yp : (face == 2 ? has_zm : has_zp));
+            if (have) {
+                const int nb = face == 0 ? (int)blockIdx.x - 1 : (face == 1 ? (int)blockIdx.x + 1 : (face == 2 ? (int)blockIdx.x - gy : (int)blockIdx.x + gy));
+                const unsigned src = (unsigned)((p - 1) & 1) * bufsz + (unsigned)nb * tilesz + (unsigned)(face ^ 1) * facesz;
+                const u64 tag = pass_tag<real>(ep, p - 1);
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) {
+                    const int k = 2 * (w & 3) + k2;
+                    const int sy_ = face == 0 ? 0 : (face == 1 ? RT + 1 : k + 1), sz_ = face == 2 ? 0 : (face == 3 ? RT + 1 : k + 1);
+                    const int y = y0 - 1 + sy_, z = z0 - 1 + sz_;
+                    if (y > sy - 2 || z > sz - 2) continue;  // past the grid: the neighbour has no such line (and nobody reads it)
+                    real x = 0;
+                    unsigned spins = 0;
+                    while (!gave_up) {
+                        asm volatile("" ::: "memory");  // a fresh load every time round (the builtin is an ordinary read to the compiler)
+                        const bool ok = get_tagged<real>(xr, src + (unsigned)k * 64u + (unsigned)lane, tag, &x);
+                        if (__builtin_amdgcn_readfirstlane((int)__all(ok))) break;
+                        if (++spins > SWEEP_SPIN_LIMIT ||
+                            ((spins & 1023u) == 0 && __hip_atomic_load(sync.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                            if (lane == 0) __hip_atomic_store(sync.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            gave_up = true;
+                        }
+                    }
+                    const int hq = ((p - 1) + y + z) & 1;  // the half of that line pass p - 1 updated
+                    L[sy_][sz_][hq][lane] = x;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- pass p on the wave's four lines
+        const unsigned dst = (unsigned)(p & 1) * bufsz + blockIdx.x * tilesz;
+        const u64 mytag = pass_tag<real>(ep, p);
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            if (!valid[l]) continue;
+            const int q = c ^ par[l];  // the half of this line that holds colour c
+            const int a = ly[l], b = lz[l];
+            const real oth = L[a][b][1 - q][lane];
+            real O, E;
+            if (q == 0) {
+                O = L[a][b][1][lane > 0 ? lane - 1 : 0];
+                E = oth;
+            } else {
+                O = oth;
+                const real t = L[a][b][0][lane < 63 ? lane + 1 : 63];
+                E = lane < 63 ? t : xR[l];
+            }
+            const real N = L[a - 1][b][q][lane], S = L[a + 1][b][q][lane], D = L[a][b - 1][q][lane], U = L[a][b + 1][q][lane];
+            const real nv = relax3d_point_rd<real>(O, E, N, S, D, U, q ? fB[l] : fA[l], hx2, hy2, hz2, rd);
+            const bool upd = q == 0 ? (lane >= 1 && lane <= M - 2) : lane <= M - 2;
+            if (upd) L[a][b][q][lane] = nv;
+            if (p + 1 < npasses) {  // the faces of the tile for the neighbours' next pass (lanes that are not updated: never read)
+                const int ry = a - 1, rz = b - 1;
+                if (ry == 0 && has_ym) put_tagged<real>(xr, dst + 0 * facesz + (unsigned)rz * 64u + (unsigned)lane, nv, mytag);
+                if (ry == RT - 1 && has_yp) put_tagged<real>(xr, dst + 1 * facesz + (unsigned)rz * 64u + (unsigned)lane, nv, mytag);
+                if (rz == 0 && has_zm) put_tagged<real>(xr, dst + 2 * facesz + (unsigned)ry * 64u + (unsigned)lane, nv, mytag);
+                if (rz == RT - 1 && has_zp) put_tagged<real>(xr, dst + 3 * facesz + (unsigned)ry * 64u + (unsigned)lane, nv, mytag);
+            }
+        }
+        // (the barrier at the top of the next pass orders this pass's LDS writes before their readers)
+    }
+    __syncthreads();
+    // ---- the tile back to memory (interior entries)
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        if (!valid[l]) continue;
+        real* row = v + g.row(y0 + ly[l] - 1, z0 + lz[l] - 1);
+        if (lane >= 1 && lane <= M - 2) row[lane] = L[ly[l]][lz[l]][0][lane];
+        if (lane <= M - 2) row[g.H + lane] = L[ly[l]][lz[l]][1][lane];
+    }
+    // launch epoch: the last workgroup to finish advances it (every workgroup has read it by then)
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const unsigned old = __hip_atomic_fetch_add(sync.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            __hip_atomic_store(sync.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync.epoch, ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Does a Relax call of `ncycles` sweeps on this level run in the resident kernel?  Rows of 33 ... 129 points (below: the
+// one-workgroup kernels; above: the level does not fit), all tiles resident at once, a context that has the GPU to itself
+// (thread-ranks and ranks of a communicator launch side by side: co-residency is not given), enough passes to pay for the load
+// and the write-back of the tile.
+bool relax3d_resident_takes(const mgx_ctx* ctx, const int n[3], int ncycles) {
+    if (!ctx->relax_resident || ctx->nranks > 1 || ctx->local_group) return false;
+    if (n[0] < 33 || n[0] > 129 || n[1] < 9 || n[2] < 9) return false;
+    const int tiles = ceil_div(n[1] - 2, RT) * ceil_div(n[2] - 2, RT);
+    if (tiles > ctx->num_cus || tiles > SWEEP_MAX_WG) return false;
+    return ncycles >= ctx->relax_resident_min;
+}
+
+template <class real>
+int relax3d_resident(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int ncycles, int zero_start) {
+    const int gy = ceil_div(n[1] - 2, RT), gz = ceil_div(n[2] - 2, RT);
+    SweepSync sync;
+    MGX_TRY_RET(sweep_state(ctx, &sync));
+    // the exchange buffer: [2][tile][4 faces][RT lines][64] elements of {value, tag}; zeroed when allocated (tag 0 is never
+    // waited for) and, because an fp32 tag has room for 2^19 launch epochs only, again every 2^18 launches
+    const size_t bytes = (size_t)2 * gy * gz * 4 * RT * 64 * 2 * sizeof(real);
+    if (ctx->resident_bytes < bytes) {
+        if (ctx->resident_buf) MGX_HIP(hipFree(ctx->resident_buf));
+        ctx->resident_buf = nullptr;
+        ctx->resident_bytes = 0;
+        MGX_HIP(hipMalloc(&ctx->resident_buf, bytes));
+        ctx->resident_bytes = bytes;
+        MGX_TRY_RET(fill_zero(ctx, ctx->resident_buf, bytes));
+    }
+    snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_resident_kernel<%s>", sizeof(real) == 8 ? "double" : "float");
+    for (int left = ncycles, first = 1; left > 0; first = 0) {  // a tag has 13 bits for the pass: at most 4000 sweeps per launch
+        const int k = left < 4000 ? left : 4000;
+        if ((++ctx->resident_launches & 0x3ffffu) == 0) MGX_TRY_RET(fill_zero(ctx, ctx->resident_buf, ctx->resident_bytes));
+        hipLaunchKernelGGL((relax3d_xs_resident_kernel<real>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2,
+                           hz2, 2 * k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)bytes, sync);
+        left -= k;
+    }
+    return MGX_OK;
+}
+template int relax3d_resident<float>(mgx_ctx*, float*, const float*, const int[3], float, float, float, int, int);
+template int relax3d_resident<double>(mgx_ctx*, double*, const double*, const int[3], double, double, double, int, int);
+
+}  // namespace mgx

@@ -30,28 +30,9 @@
 // never stored), so nothing is exchanged in z.
 #include "mgx_internal.hpp"
 #include "mgx_kernels3d.hpp"
+#include "mgx_sync.hpp"
 
 namespace mgx {
-
-typedef unsigned long long u64;
-
-struct SweepSync {
-    u64* flags;       // one word per workgroup: (epoch << 20) | (highest published red plane + 1)
-    u64* epoch;       // launch counter
-    unsigned* done;   // workgroups of the current launch that have finished
-    unsigned* abort;  // host-mapped: != 0 once a wait has given up
-};
-
-template <class T>
-__device__ __forceinline__ T ld_sc1(const T* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <class T>
-__device__ __forceinline__ void st_sc1(T* p, T v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-constexpr unsigned SWEEP_SPIN_LIMIT = 1u << 21;  // polls (each ~1 us) before a wait gives up
 
 // Tile = 64 WX pairs x WY R rows, the whole x-extent of the level (gx = 1: the host only picks shapes with 64 WX >= M - 1),
 // so the only neighbours are the tiles above and below in y.  D = lead of the red stage in planes; the ring holds the red
@@ -645,9 +626,8 @@ __global__ void __launch_bounds__(256) copy_rim3d_xs_kernel(const real* __restri
 }
 
 // ------------------------------------------------------------------ host side
-constexpr int SWEEP_MAX_WG = 2048;  // progress words per context
 
-static int sweep_state(mgx_ctx* ctx, SweepSync* out) {
+int sweep_state(mgx_ctx* ctx, SweepSync* out) {
     if (!ctx->sweep_dev) {
         const size_t bytes = 64 + sizeof(u64) * SWEEP_MAX_WG;
         void* d = nullptr;
@@ -806,7 +786,8 @@ int relax3d_xs_pp(mgx_ctx* ctx, real* v, real* w, const real* f, const int n[3],
     MGX_USE(ctx);
     MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "relax_pp3d: ncycles = %d < 0", ncycles);
     for (int d = 0; d < 3; d++) MGX_REQUIRE(valid_size(n[d]), MGX_ERR_SIZE, "relax_pp3d: size[%d] = %d is not 2^k+1 >= 3", d, n[d]);
-    const int shape = ncycles >= 2 ? sweep3d_shape<real>(ctx, n[0], n[1], n[2]) : 0;
+    // a call the resident kernel takes (all passes in one launch, in place: mgx_resident3d.hip) needs no partner array
+    const int shape = ncycles >= 2 && !relax3d_resident_takes(ctx, n, ncycles) ? sweep3d_shape<real>(ctx, n[0], n[1], n[2]) : 0;
     if (!shape) return relax3d_xs_colour_passes<real>(ctx, v, f, n, h, ncycles);
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // N3/MultiGrid3D.cpp:498-500
     int k = ncycles;
@@ -834,7 +815,8 @@ int relax3d_xs_from_zero(mgx_ctx* ctx, real* v, const real* f, const int n[3], c
 
 template <class real>
 static bool from_zero_pp_takes(const mgx_ctx* ctx, const int n[3], int ncycles, int rim_is_zero) {
-    return ncycles >= 2 && (ncycles & 1) == 0 && rim_is_zero && ctx->relax_zero_first && sweep3d_shape<real>(ctx, n[0], n[1], n[2]) == SWEEP_MID;
+    return ncycles >= 2 && (ncycles & 1) == 0 && rim_is_zero && ctx->relax_zero_first && !relax3d_resident_takes(ctx, n, ncycles) &&
+           sweep3d_shape<real>(ctx, n[0], n[1], n[2]) == SWEEP_MID;
 }
 
 // relax_from_zero with a ping-pong partner: v := 0 (N3/MultiGrid3D.cpp:634), then `ncycles` sweeps (:626).  On the
@@ -907,10 +889,10 @@ int mgx3dxs_relax_pp_f64(mgx_ctx* ctx, double* v, double* w, const double* f, co
     return mgx::relax3d_xs_pp<double>(ctx, v, w, f, n, h, ncycles, w_rim_valid);
 }
 int mgx3dxs_relax_pp_takes_f32(const mgx_ctx* ctx, const int n[3], int ncycles) {
-    return ctx && n && ncycles >= 2 && mgx::sweep3d_shape<float>(ctx, n[0], n[1], n[2]) != 0;
+    return ctx && n && ncycles >= 2 && !mgx::relax3d_resident_takes(ctx, n, ncycles) && mgx::sweep3d_shape<float>(ctx, n[0], n[1], n[2]) != 0;
 }
 int mgx3dxs_relax_pp_takes_f64(const mgx_ctx* ctx, const int n[3], int ncycles) {
-    return ctx && n && ncycles >= 2 && mgx::sweep3d_shape<double>(ctx, n[0], n[1], n[2]) != 0;
+    return ctx && n && ncycles >= 2 && !mgx::relax3d_resident_takes(ctx, n, ncycles) && mgx::sweep3d_shape<double>(ctx, n[0], n[1], n[2]) != 0;
 }
 
 #ifdef MGX_DIAGNOSTICS

@@ -1,0 +1,122 @@
+"""GPU suite: all colour passes of a Relax call in ONE launch on the cache-resident levels (relax3d_xs_resident_kernel,
+csrc/mgx_resident3d.hip) against the oracle's MultiGrid3D::Relax restatement (N3/MultiGrid3D.cpp:489-567), bit for bit.
+The workgroups hand their face lines to each other through memory, ordered by progress words: every case checks every
+word of the result; sweep counts from 1 to a few hundred move the hand-offs and the double-buffered exchange around, tile
+counts from 1 x 1 to 16 x 16 put faces, partial tiles and the extra boundary entry of 129-point rows everywhere."""
+import numpy as np
+import pytest
+
+import oracle as O
+import pde_multigrid_amd as P
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+RG = [-1, 1, 0, 2, 0.5, 3]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = P.Context(0)
+    c.set_param("relax3d.resident_min", 1)
+    yield c
+    c.close()
+
+
+def _data(n3, dtype, seed=0):
+    r = np.random.default_rng(seed)
+    shape = tuple(reversed(n3))
+    return r.uniform(-1, 1, shape).astype(dtype), r.uniform(-1, 1, shape).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n3", [(33, 33, 33), (65, 65, 65), (129, 129, 129), (129, 65, 33), (65, 129, 17), (33, 9, 129), (129, 17, 9)])
+@pytest.mark.parametrize("ncycles", [1, 2, 5])
+def test_resident_relax_matches_oracle(ctx, n3, ncycles, dtype):
+    v, f = _data(n3, dtype, seed=n3[0] + ncycles)  # random boundary values too
+    got = P.ops3dxs.relax(ctx, v, f, n3, RG, ncycles)
+    assert ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel"), ctx.last_relax_kernel()
+    ctx.sync()  # raises if a wait gave up
+    assert bits_equal(got, O.relax3d(n3, RG, v, f, ncycles, dtype=dtype))
+
+
+@pytest.mark.parametrize("n3,ncycles", [((65, 65, 65), 300), ((129, 129, 129), 40), ((33, 33, 33), 1000)])
+def test_resident_long_relax_calls(ctx, n3, ncycles):
+    """the reference's own workloads call Relax with thousands of sweeps: hundreds of hand-offs per workgroup in one launch"""
+    v, f = _data(n3, np.float32, seed=ncycles)
+    got = P.ops3dxs.relax(ctx, v, f, n3, [0, 1, 0, 1, 0, 1], ncycles)
+    assert ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+    ctx.sync()
+    assert bits_equal(got, O.relax3d(n3, [0, 1, 0, 1, 0, 1], v, f, ncycles, dtype=np.float32))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("ncycles", [1, 2, 3])
+def test_resident_from_zero(ctx, ncycles, dtype):
+    n3 = (129, 65, 65)
+    v, f = _data(n3, dtype, seed=9)
+    v[0] = v[-1] = 0
+    v[:, 0] = v[:, -1] = 0
+    v[:, :, 0] = v[:, :, -1] = 0
+    got = P.ops3dxs.relax_from_zero(ctx, v, f, n3, RG, ncycles, True)
+    assert ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+    ctx.sync()
+    assert bits_equal(got, O.relax3d(n3, RG, np.zeros_like(v), f, ncycles, dtype=dtype))
+
+
+def test_resident_many_launches_on_one_context_and_switches(ctx):
+    """the launch epoch: twenty launches in a row, other kernels in between; the off switch and the sweep-count threshold"""
+    n3 = (65, 65, 33)
+    v, f = _data(n3, np.float64, seed=1)
+    want = v
+    for k in range(20):
+        v = P.ops3dxs.relax(ctx, v, f, n3, RG, 2)
+        want = O.relax3d(n3, RG, want, f, 2, dtype=np.float64)
+    ctx.sync()
+    assert bits_equal(v, want)
+    ctx.set_param("relax3d.resident", 0)
+    try:
+        got = P.ops3dxs.relax(ctx, v, f, n3, RG, 2)
+        assert not ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+        assert bits_equal(got, O.relax3d(n3, RG, v, f, 2, dtype=np.float64))
+    finally:
+        ctx.set_param("relax3d.resident", 1)
+    ctx.set_param("relax3d.resident_min", 3)
+    try:
+        P.ops3dxs.relax(ctx, v, f, n3, RG, 2)
+        assert not ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+        P.ops3dxs.relax(ctx, v, f, n3, RG, 3)
+        assert ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+    finally:
+        ctx.set_param("relax3d.resident_min", 1)
+    big, fb = _data((257, 33, 33), np.float64)
+    P.ops3dxs.relax(ctx, big, fb, (257, 33, 33), RG, 4)  # rows too long for one wave: the colour-pass kernels
+    assert not ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+
+
+@pytest.mark.parametrize("dtype,mode", [(np.float32, 0), (np.float64, 0), (np.float32, 1)])
+def test_resident_inside_the_hierarchy(dtype, mode):
+    """V(3,3) cycles and FMG(1,3,3) on a 65^3 hierarchy with the library's defaults (three sweeps per call: the 65^3 and
+    33^3 levels run their Relax calls in the resident kernel, from zero on the way down), against the oracle's cycle"""
+    n3 = [65, 65, 65]
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    c = P.Context(0)
+    try:
+        r = np.random.default_rng(5)
+        v0 = r.uniform(-1, 1, O.shape(n3)).astype(dtype)
+        f0 = r.uniform(-1, 1, O.shape(n3)).astype(dtype)
+        mg = P.MultiGrid3D(c, n3, rg, dtype)
+        mg.upload_v(0, v0)
+        mg.upload_f(0, f0)
+        if mode:
+            mg.FullMultiGridVCycle(0, 1, 3, 3)
+        else:
+            mg.VCycle(0, 3, 3)
+            mg.VCycle(0, 3, 3)
+        assert c.last_relax_kernel().startswith("relax3d_xs_resident_kernel"), c.last_relax_kernel()
+        got = mg.download_v(0)
+        mg.close()
+        c.sync()
+        want = O.cycle3d(n3, rg, mode=mode, v0=1, v1=3, v2=3, reps=1 if mode else 2, v=v0, f=f0, dtype=dtype)
+        assert bits_equal(got, want)
+    finally:
+        c.close()

@@ -17,6 +17,7 @@ RG = [-1, 1, 0, 2, 0.5, 3]  # anisotropic box: hx != hy != hz
 def ctx():
     c = P.Context(0)
     c.set_param("relax3d.fused", 1)
+    c.set_param("relax3d.resident", 0)  # these cases are about the one-launch-per-sweep kernels (tests/test_gpu_resident.py: the other form)
     yield c
     c.close()
 
