@@ -78,9 +78,10 @@ int mgx_device_count(int* count);
 int mgx_ctx_create(int device, mgx_ctx** out);
 int mgx_ctx_destroy(mgx_ctx* ctx);
 int mgx_ctx_sync(mgx_ctx* ctx);                 /* waits for the compute and comm streams, then mgx_ctx_check */
-/* MGX_OK unless an inter-workgroup wait of a one-launch red+black sweep (mgx3dxs_relax_pp) has given up on this
- * context -- its workgroups were not resident together; results of that launch are invalid ("relax3d.fused" = 0 avoids
- * the kernel).  Meaningful after a synchronisation. */
+/* MGX_OK unless an inter-workgroup wait of a kernel whose workgroups hand data to each other (the one-launch red+black
+ * sweep of mgx3dxs_relax_pp; the resident Relax kernel that runs all passes of a long Relax call on a cache-resident
+ * level) has given up on this context -- its workgroups were not resident together; results of that launch are invalid
+ * ("relax3d.fused" = 0 / "relax3d.resident" = 0 avoid the kernels).  Meaningful after a synchronisation. */
 int mgx_ctx_check(mgx_ctx* ctx);
 int mgx_ctx_device(const mgx_ctx* ctx, int* device);
 /* tuning knobs of the x-split smoother kernel (speed only, never results): "relax3d.ty" waves
@@ -94,6 +95,8 @@ int mgx_ctx_device(const mgx_ctx* ctx, int* device);
  * ".pzchunk" coarse planes per run (0 automatic), ".tyw" waves per workgroup, ".cr" coarse rows per lane, ".rows" fine rows
  * per wave of the pipelined kernel (0 = by level size, 2, 4), ".xcd" 0/1/2 XCD-aware block order, ".rcp" 0/1: with
  * power-of-two squared spacings the residual multiplies by the exact reciprocals instead of dividing (same bits);
+ * "relax3d.resident" 0/1 and "relax3d.resident_min" (sweeps per call, default 3): all colour passes of a Relax call on a level
+ * of 33 ... 129 points per row in one launch (single-rank contexts only);
  * "rr3d.black" 0 / 1 / 2: the last black pass of the pre-smoothing inside the residual+restrict launch -- off / on the
  * HBM-bound levels / wherever the geometry allows (tests), "rr3d.black_waves" 0 (by precision), 12, 16 waves per workgroup.
  * Unknown names and out-of-range values are rejected (MGX_ERR_INVALID). */

@@ -907,13 +907,14 @@ int mgx_sweep_debug_read(mgx_ctx* ctx, long long* host, size_t count) {
 }
 #endif
 
-// 0 while no inter-workgroup wait of a fused sweep has given up on this context; MGX_ERR_HIP afterwards (results of that
+// 0 while no inter-workgroup wait (one-launch sweep, resident Relax) has given up on this context; MGX_ERR_HIP afterwards (results of that
 // launch are garbage).  Meaningful after a synchronisation (mgx_ctx_sync calls it).
 int mgx_ctx_check(mgx_ctx* ctx) {
     MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
     if (ctx->sweep_abort && *(volatile unsigned*)ctx->sweep_abort)
-        return mgx::fail(MGX_ERR_HIP, "a fused red-black sweep gave up waiting for a neighbouring workgroup (workgroups not resident together?); "
-                                      "its results are invalid -- set \"relax3d.fused\" to 0");
+        return mgx::fail(MGX_ERR_HIP, "a kernel whose workgroups wait for each other (one-launch sweep, resident Relax) gave up waiting for a "
+                                      "neighbouring workgroup (workgroups not resident together?); its results are invalid -- set "
+                                      "\"relax3d.fused\" and \"relax3d.resident\" to 0");
     return MGX_OK;
 }
 }
