@@ -4,6 +4,8 @@ by hand on the GPU box, not part of the suites): random anisotropic 2^k+1 shapes
 modes, both precisions, V-cycles and FMG, boxes with and without power-of-two spacings.
 
     python3 tools/fuzz_cycles.py [cases] [seed]
+MGX_PARAMS=name=value,... sets library parameters first (e.g. rr3d.black=2,relax3d.resident_min=1: the fused way down and
+the resident Relax kernel on every level that has the geometry); MGX_FUZZ_SWEEPS=n: sweep counts up to n - 1 (default 4).
 """
 import os
 import sys
@@ -19,6 +21,9 @@ import pde_multigrid_amd as P  # noqa: E402
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = P.Context(0)
+for kv in filter(None, os.environ.get("MGX_PARAMS", "").split(",")):
+    ctx.set_param(kv.split("=")[0], int(kv.split("=")[1]))
+SWEEPS = int(os.environ.get("MGX_FUZZ_SWEEPS", "4"))
 SZ = [3, 5, 9, 17, 33, 65, 129, 257]
 bad = 0
 for c in range(cases):
@@ -32,7 +37,7 @@ for c in range(cases):
     for d in range(dim):
         a = float(rng.choice([0.0, -1.0, 0.5]))
         box += [a, a + float(rng.choice([1.0, 2.0, 1.5, 20.0]))]
-    v1, v2 = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+    v1, v2 = int(rng.integers(0, SWEEPS)), int(rng.integers(0, SWEEPS))
     maxlev = O.num_grids(min(n))
     nlev = int(rng.integers(1, maxlev + 1)) if rng.random() < 0.5 else 0
     fmg = rng.random() < 0.3

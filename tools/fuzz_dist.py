@@ -17,6 +17,9 @@ import oracle as O  # noqa: E402
 import pde_multigrid_amd as P  # noqa: E402
 from test_gpu_dist import run_ranks  # noqa: E402
 
+# MGX_PARAMS=name=value,... : library parameters of the ranks' contexts (e.g. rr3d.black=2: the fused way down on slabs)
+PARAMS = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in filter(None, os.environ.get("MGX_PARAMS", "").split(","))}
+
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
@@ -36,7 +39,7 @@ for c in range(cases):
     v = rng.uniform(-1, 1, O.shape(n)).astype(dtype)
     f = rng.uniform(-1, 1, O.shape(n)).astype(dtype)
     ctx = P.Context(0)
-    mg = P.MultiGrid3D(ctx, n, box, dtype, residual_mode=mode)
+    mg = P.MultiGrid3D(ctx, n, box, dtype, residual_mode=mode)  # the reference run: library defaults
     mg.upload_f(0, f)
     mg.upload_v(0, v)
     if fmg:
@@ -49,7 +52,7 @@ for c in range(cases):
     try:
         ib = [0, None, 200_000, 2_000_000][int(rng.integers(0, 4))]  # overlapped / library default / mixed thresholds
         got, info = run_ranks(nr, n, box, dtype, v1, v2, reps, mp, mode=mode, v0=v, f0=f, fmg=fmg, delay_us=200, join_timeout=120,
-                              inline_bytes=ib)
+                              inline_bytes=ib, params=PARAMS)
         ok = got.tobytes() == want.tobytes()
         what = "levels dist/all %s inline_bytes=%s" % (info[0], ib)
     except AssertionError as e:
