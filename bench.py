@@ -314,6 +314,37 @@ def main():
     smoother_mlups = 2 * my_lups_per_launch * args.smoother_sweeps / (ms * 1e-3) / 1e6
     barrier()
 
+    # ---- the second kernel of the finest level: last black pass + residual + restrict in one launch (HIP events) -------
+    down = None
+    if not slabbed:
+        import ctypes as C
+        sfx = "f64" if args.dtype == "f64" else "f32"
+        g0, g1 = mg.grid(0), mg.grid(1) if nlev > 1 else None
+        n0 = (C.c_int * 3)(*g0.sizeXYZ)
+        n1 = (C.c_int * 3)(*g1.sizeXYZ) if g1 is not None else None
+        if g1 is not None and getattr(P.lib, "mgx3dxs_relax_rr_takes_" + sfx)(ctx._h, n0, n1):
+            ct = C.c_double if args.dtype == "f64" else C.c_float
+            hh = (ct * 3)(g0.h_x, g0.h_y, g0.h_z)
+            fn = getattr(P.lib, "mgx3dxs_relax_rr_slab_" + sfx)
+
+            def fused():
+                P.check(fn(ctx._h, C.c_void_p(g0.d_v), C.c_void_p(g0.d_f), n0, C.c_int(0), hh, C.c_int(0), C.c_void_p(g1.d_f), n1,
+                           C.c_int(0), C.c_int(1), C.c_int(g1.sizeXYZ[2] - 1)))
+            fused()
+            ctx.sync()
+            reps = 10
+            ctx.record(e0)
+            for _ in range(reps):
+                fused()
+            ctx.record(e1)
+            dms = ctx.elapsed_ms(e0, e1) / reps  # includes the zero fill of the coarse planes (1 / 8 word per point)
+            nc = g1.sizeXYZ[0]
+            dbytes = wbytes * (2.0 * (n - 2) ** 3 + (nc - 2) ** 3)  # red half of v + f in, black half + coarse out
+            down = {"kernel": ctx.last_rr_kernel(), "what": "last black pass of the pre-smoothing + residual + restrict, finest level, one launch (timed with the zero fill of the coarse planes the stand-alone entry does first)",
+                    "avg_launch_us": round(dms * 1e3, 2), "algorithmic_bytes_per_launch": dbytes,
+                    "achieved": round(dbytes / (dms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(dbytes / (dms * 1e-3) / HBM_PEAK_BPS, 4)}
+    barrier()
+
     # ---- result check: one cycle from v = 0 against the oracle's committed known answer ----
     check = None
     if not args.no_check and args.v1 == 2 and args.v2 == 2:
@@ -442,6 +473,8 @@ def main():
             },
             "result_check": check,
         }
+        if down is not None:
+            out["roofline_down"] = down
         if one_gpu is not None:
             out["config"]["one_gpu_same_problem"] = one_gpu
         if comm is not None:
