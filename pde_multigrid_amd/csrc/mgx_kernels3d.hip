@@ -1281,23 +1281,19 @@ __global__ void __launch_bounds__(256) interpolate3d_xs_kernel(real* __restrict_
 // only the global fine planes [zmin, zmax) are written.
 template <class real>
 __global__ void __launch_bounds__(256) correct_pset3d_xs_kernel(real* __restrict__ fine, int fx, int fy, const real* __restrict__ coarse,
-                                                                int cx, int cy, int PW, int PH, int gx0, int gy0, int gx1, int fzoff = 0,
-                                                                int czoff = 0, int pzbeg = 0, int zmin = 1, int zmax = 0x7fffffff) {
-    // ONE launch for both parts of P (they are disjoint): blocks [0, gx0 gy0) take the cell rows py % PH == 0, the rest the cell
-    // columns at the tile edges (their cells of other rows)
+                                                                int cx, int cy, int PW, int PH, int part, int fzoff = 0, int czoff = 0,
+                                                                int pzbeg = 0, int zmin = 1, int zmax = 0x7fffffff) {
     const Geo<XSplit, real> gf(fx, fy), gc(cx, cy);
     const int M = (fx + 1) >> 1;
     const int pz = pzbeg + blockIdx.z;
     int i, py;
-    if ((int)blockIdx.x < gx0 * gy0) {
-        const int bx = blockIdx.x % gx0, by = blockIdx.x / gx0;
-        i = bx * 64 + threadIdx.x;
-        py = (by * blockDim.y + threadIdx.y) * PH;
+    if (part == 0) {
+        i = blockIdx.x * 64 + threadIdx.x;
+        py = (blockIdx.y * blockDim.y + threadIdx.y) * PH;
     } else {
-        const int b = blockIdx.x - gx0 * gy0;
-        const int c = b % gx1, by = b / gx1;  // column group c >> 1 (1, 2, ...), its pair PW g - 1 (c even) or PW g (c odd)
+        const int c = blockIdx.x;  // column group c >> 1 (1, 2, ...), its pair PW g - 1 (c even) or PW g (c odd)
         i = ((c >> 1) + 1) * PW - 1 + (c & 1);
-        py = by * 256 + threadIdx.y * 64 + threadIdx.x;
+        py = blockIdx.y * 256 + threadIdx.y * 64 + threadIdx.x;
         if (py % PH == 0) return;
     }
     if (i >= M - 1 || py >= cy - 1) return;
@@ -2608,11 +2604,17 @@ static void corr_pset_launch(mgx_ctx* ctx, real* v, int sx, int sy, int fzoff, c
     const int pzbeg = zmin / 2, pzend = (zmax - 1) / 2 + 1;
     if (pzend <= pzbeg) return;
     const int nk = (cn[1] - 2) / PH + 1;
-    const int gx0 = ceil_div(M - 1, 64), gy0 = ceil_div(nk, 4), gx1 = 2 * ((M - 1) / PW), gy1 = ceil_div(cn[1] - 1, 256);
-    hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(gx0 * gy0 + gx1 * gy1, 1, pzend - pzbeg), blk(), 0, ctx->compute, v, sx, sy,
-                       coarse_v, cn[0], cn[1], PW, PH, gx0, gy0, gx1 > 0 ? gx1 : 1, fzoff, czoff, pzbeg, zmin, zmax);
+    hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ceil_div(M - 1, 64), ceil_div(nk, 4), pzend - pzbeg), blk(), 0, ctx->compute, v,
+                       sx, sy, coarse_v, cn[0], cn[1], PW, PH, 0, fzoff, czoff, pzbeg, zmin, zmax);
+    const int ncol = 2 * ((M - 1) / PW);
+    if (ncol > 0)
+        hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ncol, ceil_div(cn[1] - 1, 256), pzend - pzbeg), blk(), 0, ctx->compute, v, sx,
+                           sy, coarse_v, cn[0], cn[1], PW, PH, 1, fzoff, czoff, pzbeg, zmin, zmax);
 }
 
+// the red pass through the correction over the LOCAL planes [zb, ze) of v: `coarse_sh` = the coarse array shifted so that
+// local fine plane z interpolates from its planes z >> 1 (+ 1), szl = global plane count - global index of local plane 0,
+// ckmax = last plane of coarse_sh that exists; colour = 0 + parity of the slab's global offset
 template <class real>
 static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zb, int ze, real hx2, real hy2, real hz2, int colour,
                             const real* coarse_sh, int cx, int cy, int szl, int ckmax) {
