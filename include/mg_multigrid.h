@@ -168,6 +168,14 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         /* known to be 0: the coarse error then starts a cycle without a zero fill.  Set by create and  */ \
         /* zero_v, cleared by upload_v.                                                                  */ \
         unsigned char v_rim_zero[MG_MAX_LEVELS];                                                         \
+        /* use_graph != 0: VCycle(0, v1, v2) is captured into a HIP graph (both streams, the RCCL calls */ \
+        /* included) and replayed, as mgMultiGrid3D does -- opt-in: it needs collectives that can be    */ \
+        /* captured (RCCL or a single rank; mgx_comm_capturable), and RCCL under capture between        */ \
+        /* different GPUs has not been run anywhere yet.  A failed capture is an error, not a fallback. */ \
+        int use_graph;                                                                                   \
+        void* graph_exec;                                                                                \
+        long long graph_key;                                                                             \
+        int graph_warm;            /* the first cycle runs eagerly: lazy allocations cannot be captured */ \
     } mgDistMultiGrid3D_##R;                                                                             \
     int mgDistMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6], \
                                        int min_planes, mgDistMultiGrid3D_##R** out);                     \

@@ -429,6 +429,9 @@ int mgx_comm_init(mgx_ctx* ctx, const void* host_id_bytes, int rank, int nranks)
 int mgx_comm_init_rehearsal(mgx_ctx* ctx, const void* host_id_bytes, int virtual_rank, int virtual_nranks);
 int mgx_comm_destroy(mgx_ctx* ctx);
 int mgx_comm_rank(const mgx_ctx* ctx, int* rank, int* nranks);
+/* 1 when the context's collectives can be captured into a HIP graph (an RCCL communicator, or a single rank without
+ * one); 0 with the in-process test transport, whose exchanges are coordinated on the host */
+int mgx_comm_capturable(const mgx_ctx* ctx);
 /* the number of ranks the communicator itself reports (ncclCommCount) and the RCCL version in use (ncclGetVersion) */
 int mgx_comm_info(const mgx_ctx* ctx, int* ranks_seen, int* rccl_version);
 /* Test transport: `nranks` host threads of one process, one context each, all on the same device, so that the

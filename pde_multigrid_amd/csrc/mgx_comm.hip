@@ -386,6 +386,8 @@ int mgx_comm_rank(const mgx_ctx* ctx, int* rank, int* nranks) {
 
 // what the communicator itself reports: the number of ranks RCCL sees (ncclCommCount; the local test transport: its
 // group size; no communicator: 1) and the RCCL version the library is running on (ncclGetVersion, e.g. 22105)
+int mgx_comm_capturable(const mgx_ctx* ctx) { return ctx && !ctx->local_group && (ctx->rccl_comm || ctx->nranks == 1); }
+
 int mgx_comm_info(const mgx_ctx* ctx, int* ranks_seen, int* rccl_version) {
     MGX_REQUIRE(ctx && ranks_seen && rccl_version, MGX_ERR_INVALID, "NULL argument");
     *ranks_seen = ctx->nranks;

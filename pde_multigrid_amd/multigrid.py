@@ -821,7 +821,8 @@ def _dist_struct(ct):
         _fields_ = [("slabs", C.POINTER(C.POINTER(Slab3D))), ("numDist", C.c_int), ("numGrids", C.c_int), ("maxGrids", C.c_int),
                     ("tail", C.c_void_p), ("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
                     ("residual_mode", C.c_int), ("d_share", C.c_void_p), ("d_bplane", C.c_void_p), ("d_norm", C.c_void_p),
-                    ("norm_count", C.c_int), ("inline_bytes", C.c_longlong), ("v_rim_zero", C.c_ubyte * 32)]
+                    ("norm_count", C.c_int), ("inline_bytes", C.c_longlong), ("v_rim_zero", C.c_ubyte * 32),
+                    ("use_graph", C.c_int), ("graph_exec", C.c_void_p), ("graph_key", C.c_longlong), ("graph_warm", C.c_int)]
 
     return Slab3D, DistMultiGrid3D
 
@@ -833,7 +834,7 @@ class DistMultiGrid3D(_MGBase):
     _prefix = "mgDistMultiGrid3D"
 
     def __init__(self, ctx, finestGridSizeXYZ, rng, dtype=np.float64, nlevels=0, residual_mode=REF_COMPAT, min_planes=4,
-                 inline_bytes=None):
+                 inline_bytes=None, use_graph=False):
         self.ctx = ctx
         self.dtype = np.dtype(dtype)
         self._sfx, self._ct = _ct(dtype)
@@ -847,6 +848,7 @@ class DistMultiGrid3D(_MGBase):
         self._mg.contents.residual_mode = int(residual_mode)
         if inline_bytes is not None:  # None: the library default (mg_multigrid.h); 0: every level overlapped
             self._mg.contents.inline_bytes = int(inline_bytes)
+        self._mg.contents.use_graph = int(bool(use_graph))  # opt-in: VCycle(0, ...) captured (RCCL calls included) and replayed
 
     @property
     def inline_bytes(self):

@@ -366,3 +366,44 @@ def test_local_transport_allreduce_and_allgather_bits():
     for c in ctxs:
         c.close()
     group.close()
+
+
+@pytest.mark.timeout(200)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dist_vcycle_graph_replay_one_rank(dtype):
+    """use_graph on the slab hierarchy (opt-in): the cycle from level 0 is captured once per set of host-side flags and replayed;
+    five cycles of one rank against the oracle (the first ones capture again while the flags settle)"""
+    n3 = [129, 65, 65]
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    c = P.Context(0)
+    try:
+        r = np.random.default_rng(8)
+        v0 = r.uniform(-1, 1, O.shape(n3)).astype(dtype)
+        f0 = r.uniform(-1, 1, O.shape(n3)).astype(dtype)
+        mg = P.DistMultiGrid3D(c, n3, rg, dtype, min_planes=8, use_graph=True)
+        mg.upload_f(0, f0)
+        mg.upload_v(0, v0)
+        for _ in range(5):
+            mg.VCycle(0, 2, 2)
+        got = np.full(O.shape(n3), np.nan, dtype)
+        mg.download_v_into(0, got)
+        mg.close()
+        assert bits_equal(got, O.cycle3d(n3, rg, mode=0, v1=2, v2=2, reps=5, v=v0, f=f0, dtype=dtype))
+    finally:
+        c.close()
+
+
+@pytest.mark.timeout(200)
+def test_rehearsed_rank_with_graph_replay_runs():
+    """one of eight ranks rehearsed (RCCL self send / recv of every message) with the cycle captured into a HIP graph: the RCCL
+    calls are part of the capture.  Values are meaningless in a rehearsal; this checks that capture and replay work at all."""
+    c = P.Context(0)
+    try:
+        c.comm_init_rehearsal(P.Context.unique_id(), 4, 8)
+        mg = P.DistMultiGrid3D(c, [129, 129, 257], R3, np.float64, min_planes=8, use_graph=True)
+        for _ in range(4):
+            mg.VCycle(0, 2, 2)
+        c.sync()
+        mg.close()
+    finally:
+        c.close()

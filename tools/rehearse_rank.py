@@ -43,12 +43,14 @@ if one_gpu_ms <= 0:
     ctx.close()
 print("one GPU, the whole %d^3 hierarchy: %.3f ms per V(2,2) cycle -> perfect %d-way share %.3f ms" % (n, one_gpu_ms, nranks, one_gpu_ms / nranks))
 rows = []
-modes = ((None, "library default (inline_bytes = 96 MB)"), (0, "every level overlapped"), (1 << 40, "every level inline"))
-for inline_bytes, label in (modes[:1] if only_rank >= 0 else modes):
+modes = ((None, "library default (inline_bytes = 96 MB)"), (0, "every level overlapped"), (1 << 40, "every level inline"),
+         (-1, "library default, cycle replayed from a HIP graph"))
+for inline_bytes, label in ((modes[0], modes[3]) if only_rank >= 0 else modes):
     for vr in ((only_rank,) if only_rank >= 0 else (0, nranks // 2, nranks - 1)):
         ctx = P.Context(0)
         ctx.comm_init_rehearsal(P.Context.unique_id(), vr, nranks)
-        mg = P.DistMultiGrid3D(ctx, [n] * 3, R3, np.float64, min_planes=32, inline_bytes=inline_bytes)
+        mg = P.DistMultiGrid3D(ctx, [n] * 3, R3, np.float64, min_planes=32, inline_bytes=None if inline_bytes == -1 else inline_bytes,
+                               use_graph=inline_bytes == -1)
         ms = timed(ctx, mg)
         nd = mg.numDist
         mg.close()
