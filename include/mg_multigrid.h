@@ -176,6 +176,13 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         void* graph_exec;                                                                                \
         long long graph_key;                                                                             \
         int graph_warm;            /* the first cycle runs eagerly: lazy allocations cannot be captured */ \
+        /* pack_halos != 0: the ghost exchange behind a colour pass carries only the half-rows of the    */ \
+        /* colour the pass changed (d_stage: 2 send + 2 receive arrays of stage_half elements); 0        */ \
+        /* (default): whole planes -- at 1025^3 on 8 ranks a plane's transfer hides behind the interior  */ \
+        /* launch and the pack / unpack launches only add latency (rehearsal: 4.52 against 4.36 ms)      */ \
+        int pack_halos;                                                                                  \
+        real* d_stage;                                                                                   \
+        size_t stage_half;                                                                               \
     } mgDistMultiGrid3D_##R;                                                                             \
     int mgDistMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6], \
                                        int min_planes, mgDistMultiGrid3D_##R** out);                     \

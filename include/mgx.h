@@ -456,6 +456,20 @@ int mgx_comm_halo_exchange(mgx_ctx* ctx, const void* send_to_lower, size_t count
                            size_t count_from_lower, const void* send_to_upper, size_t count_to_upper,
                            void* recv_from_upper, size_t count_from_upper, int elem_bytes);
 int mgx_comm_wait(mgx_ctx* ctx);
+/* Half planes for the ghost exchange behind a colour pass: only the half-rows that hold `colour` (even-x half where
+ * colour + y + z is even, z = the plane's GLOBAL index) are packed into a staging array of mgx3dxs_halfplane_elems
+ * elements (compute stream), exchanged with mgx_comm_halo_exchange, and unpacked into the ghost plane on the stream the
+ * receive was enqueued on (mgx_comm_wait covers it).  Two planes per call (either may be NULL). */
+size_t mgx3dxs_halfplane_elems_f32(int sx, int sy);
+size_t mgx3dxs_halfplane_elems_f64(int sx, int sy);
+int mgx3dxs_halo_pack_f32(mgx_ctx* ctx, const float* plane_a, int z_a, float* stage_a, const float* plane_b, int z_b, float* stage_b, int sx,
+                          int sy, int colour);
+int mgx3dxs_halo_pack_f64(mgx_ctx* ctx, const double* plane_a, int z_a, double* stage_a, const double* plane_b, int z_b, double* stage_b,
+                          int sx, int sy, int colour);
+int mgx3dxs_halo_unpack_f32(mgx_ctx* ctx, const float* stage_a, float* plane_a, int z_a, const float* stage_b, float* plane_b, int z_b, int sx,
+                            int sy, int colour);
+int mgx3dxs_halo_unpack_f64(mgx_ctx* ctx, const double* stage_a, double* plane_a, int z_a, const double* stage_b, double* plane_b, int z_b,
+                            int sx, int sy, int colour);
 /* on != 0: from now on collectives are enqueued on the COMPUTE stream, in order with the kernels (no overlap, no
  * cross-stream events; mgx_comm_wait is then a no-op); 0: back to the comm stream.  Every rank switches at the same
  * points of its schedule.  The slab driver switches per level (mgDistMultiGrid3D_*: inline_bytes). */

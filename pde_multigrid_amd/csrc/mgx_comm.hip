@@ -486,6 +486,66 @@ int mgx_comm_wait(mgx_ctx* ctx) {
     return MGX_OK;
 }
 
+}  // extern "C" (a template follows)
+
+// ---- half planes: a colour pass changes ONE colour of a plane, i.e. one half-row of every x-split row (the even-x half where
+// (colour + y + z) is even, the odd-x half elsewhere), so a ghost exchange behind a pass needs to carry only those: the changed
+// half-rows of a plane are packed into a staging array (row pitch = the longer half), sent, and unpacked into the ghost plane
+// on the stream the receive is enqueued on (so the unpacking overlaps the interior launch like the transfer itself).
+template <class real>
+__global__ void __launch_bounds__(256) halo_halfrows_kernel(const real* __restrict__ srcA, real* __restrict__ dstA, int zA,
+                                                            const real* __restrict__ srcB, real* __restrict__ dstB, int zB, int sx, int sy,
+                                                            int colour, int pack) {
+    // blockIdx.y: plane A / B; blockIdx.x: row.  pack: plane -> staging; else staging -> plane
+    const bool second = blockIdx.y != 0;
+    const real* src = second ? srcB : srcA;
+    real* dst = second ? dstB : dstA;
+    if (!src || !dst) return;
+    const int z = second ? zB : zA, y = blockIdx.x;
+    const int al = 128 / (int)sizeof(real);
+    const int H = (((sx + 1) >> 1) + al - 1) / al * al, H2 = ((sx >> 1) + al - 1) / al * al, P = H + H2;
+    const int q = (colour + y + z) & 1;          // the half of row y that holds the colour
+    const int n = q ? H2 : H;
+    const size_t prow = (size_t)y * P + (q ? H : 0), srow = (size_t)y * H;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (pack) dst[srow + i] = src[prow + i];
+        else dst[prow + i] = src[srow + i];
+    }
+}
+
+#define MGX_HALFROWS(SFX, real)                                                                                              \
+    size_t mgx3dxs_halfplane_elems_##SFX(int sx, int sy) {                                                                   \
+        const int al = 128 / (int)sizeof(real);                                                                              \
+        return (size_t)sy * (size_t)((((sx + 1) >> 1) + al - 1) / al * al);                                                  \
+    }                                                                                                                        \
+    int mgx3dxs_halo_pack_##SFX(mgx_ctx* ctx, const real* plane_a, int z_a, real* stage_a, const real* plane_b, int z_b,    \
+                                real* stage_b, int sx, int sy, int colour) {                                                 \
+        MGX_REQUIRE(ctx && sx >= 3 && sy >= 3 && (colour == 0 || colour == 1), MGX_ERR_INVALID, "halo_pack: bad argument");  \
+        MGX_USE(ctx);                                                                                                        \
+        if (ctx->nranks == 1 || ((!plane_a || !stage_a) && (!plane_b || !stage_b))) return MGX_OK;                           \
+        hipLaunchKernelGGL((halo_halfrows_kernel<real>), dim3(sy, 2), dim3(256), 0, ctx->compute, plane_a, stage_a, z_a,     \
+                           plane_b, stage_b, z_b, sx, sy, colour, 1);                                                        \
+        MGX_LAUNCH_CHECK();                                                                                                  \
+        return MGX_OK;                                                                                                       \
+    }                                                                                                                        \
+    int mgx3dxs_halo_unpack_##SFX(mgx_ctx* ctx, const real* stage_a, real* plane_a, int z_a, const real* stage_b,           \
+                                  real* plane_b, int z_b, int sx, int sy, int colour) {                                      \
+        MGX_REQUIRE(ctx && sx >= 3 && sy >= 3 && (colour == 0 || colour == 1), MGX_ERR_INVALID, "halo_unpack: bad argument"); \
+        MGX_USE(ctx);                                                                                                        \
+        if (ctx->nranks == 1 || ((!plane_a || !stage_a) && (!plane_b || !stage_b))) return MGX_OK;                           \
+        /* behind the receive, on the stream it was enqueued on: mgx_comm_wait covers it */                                  \
+        hipLaunchKernelGGL((halo_halfrows_kernel<real>), dim3(sy, 2), dim3(256), 0, cstream(ctx), stage_a, plane_a, z_a,     \
+                           stage_b, plane_b, z_b, sx, sy, colour, 0);                                                        \
+        MGX_LAUNCH_CHECK();                                                                                                  \
+        return MGX_OK;                                                                                                       \
+    }
+extern "C" {
+MGX_HALFROWS(f32, float)
+MGX_HALFROWS(f64, double)
+}
+#undef MGX_HALFROWS
+
+extern "C" {
 // Inline mode: collectives are enqueued on the compute stream, in order with the kernels, instead of on the comm stream
 // behind an event -- no overlap with computation, but also none of the two cross-stream dependencies an overlapped
 // exchange costs (measured 12.5 us each on MI355X / ROCm 7.2 against 2.5 us between kernels of one stream,

@@ -822,7 +822,8 @@ def _dist_struct(ct):
                     ("tail", C.c_void_p), ("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
                     ("residual_mode", C.c_int), ("d_share", C.c_void_p), ("d_bplane", C.c_void_p), ("d_norm", C.c_void_p),
                     ("norm_count", C.c_int), ("inline_bytes", C.c_longlong), ("v_rim_zero", C.c_ubyte * 32),
-                    ("use_graph", C.c_int), ("graph_exec", C.c_void_p), ("graph_key", C.c_longlong), ("graph_warm", C.c_int)]
+                    ("use_graph", C.c_int), ("graph_exec", C.c_void_p), ("graph_key", C.c_longlong), ("graph_warm", C.c_int),
+                    ("pack_halos", C.c_int), ("d_stage", C.c_void_p), ("stage_half", C.c_size_t)]
 
     return Slab3D, DistMultiGrid3D
 
@@ -834,7 +835,7 @@ class DistMultiGrid3D(_MGBase):
     _prefix = "mgDistMultiGrid3D"
 
     def __init__(self, ctx, finestGridSizeXYZ, rng, dtype=np.float64, nlevels=0, residual_mode=REF_COMPAT, min_planes=4,
-                 inline_bytes=None, use_graph=False):
+                 inline_bytes=None, use_graph=False, pack_halos=None):
         self.ctx = ctx
         self.dtype = np.dtype(dtype)
         self._sfx, self._ct = _ct(dtype)
@@ -849,6 +850,8 @@ class DistMultiGrid3D(_MGBase):
         if inline_bytes is not None:  # None: the library default (mg_multigrid.h); 0: every level overlapped
             self._mg.contents.inline_bytes = int(inline_bytes)
         self._mg.contents.use_graph = int(bool(use_graph))  # opt-in: VCycle(0, ...) captured (RCCL calls included) and replayed
+        if pack_halos is not None:  # None: the library default (half planes behind colour passes when there are neighbours)
+            self._mg.contents.pack_halos = int(bool(pack_halos))
 
     @property
     def inline_bytes(self):

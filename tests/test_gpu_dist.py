@@ -23,7 +23,8 @@ DELAY_US = 300  # a colour pass of these grids takes 5-50 us: every transfer arr
 
 
 def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COMPAT, v0=None, f0=None, nlevels=0, fmg=0,
-              delay_us=DELAY_US, drop_waits=False, extra=None, join_timeout=100, inline_bytes=0, v_levels=None, params=None):
+              delay_us=DELAY_US, drop_waits=False, extra=None, join_timeout=100, inline_bytes=0, v_levels=None, params=None,
+              pack_halos=None):
     """inline_bytes = 0: every level runs the OVERLAPPED schedule (comm stream, edge planes first) -- what these tests were
     written for; None: the library default (small levels exchange inline on the compute stream); a number: that threshold"""
     ctxs = [P.Context(0) for _ in range(nranks)]
@@ -40,7 +41,7 @@ def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COM
     def worker(r):
         try:
             mg = P.DistMultiGrid3D(ctxs[r], n3, rng, dtype, nlevels=nlevels, residual_mode=mode, min_planes=min_planes,
-                                   inline_bytes=inline_bytes)
+                                   inline_bytes=inline_bytes, pack_halos=pack_halos)
             info[r] = (mg.numDist, mg.numGrids)
             if f0 is not None:
                 mg.upload_f(0, f0)
@@ -407,3 +408,19 @@ def test_rehearsed_rank_with_graph_replay_runs():
         mg.close()
     finally:
         c.close()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("nranks,inline_bytes,dtype", [(2, 0, np.float64), (4, None, np.float32), (8, 0, np.float64)])
+def test_dist_half_plane_exchanges(nranks, inline_bytes, dtype):
+    """pack_halos: behind a colour pass only the half-rows of the colour it changed travel (packed on the compute stream,
+    unpacked on the stream of the receive); whole planes where both colours changed.  V(2,2) x 2 and the fused way down
+    forced, both exchange modes, against the oracle"""
+    n3 = [129, 65, 129]
+    rng = np.random.default_rng(500 + nranks)
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    v0 = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    f0 = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    got, info = run_ranks(nranks, n3, rg, dtype, 2, 2, 2, 8, v0=v0, f0=f0, inline_bytes=inline_bytes, params={"rr3d.black": 2},
+                          pack_halos=True)
+    assert bits_equal(got, O.cycle3d(n3, rg, mode=0, v1=2, v2=2, reps=2, v=v0, f=f0, dtype=dtype))
