@@ -48,7 +48,6 @@ struct mgx_ctx {
     int relax_resident_min = 3;  // ... from this many sweeps per call on
     void* resident_buf = nullptr;  // its exchange buffer (tagged face lines)
     size_t resident_bytes = 0;
-    unsigned resident_launches = 0;
     int sweep_ilv = 0;     // that kernel with its memory instructions interleaved with the arithmetic instead of issued first
     int sweep_lead = 0;    // planes the red stage of that kernel runs ahead of the black stage (0 = default)
     int sweep_dbg = 0;     // diagnostic builds: 1 = cycle stamps, + 2 * ablation bits (sweep3d_xs_kernel)

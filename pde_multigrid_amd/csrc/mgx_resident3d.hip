@@ -26,41 +26,34 @@ namespace mgx {
 
 constexpr int RT = 8;  // tile edge in rows and in planes
 
-// one exchanged element = {value, tag}: 2 x 32 bit (fp32) or 2 x 64 bit (fp64), accessed as ONE aligned 8- / 16-byte unit
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+// one exchanged element = {value, tag}: 16 bytes in both precisions (the tag = launch epoch << 20 | pass + 1 is 64 bits wide:
+// it never wraps and is never 0, the content of a fresh buffer), stored and loaded as ONE aligned 16-byte unit
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 template <class real>
 __device__ __forceinline__ void put_tagged(__amdgpu_buffer_rsrc_t r, unsigned elem, real x, u64 tag) {
+    u32x4_t t;
     if constexpr (sizeof(real) == 4) {
-        u32x2_t t;
         t.x = __float_as_uint(x);
-        t.y = (unsigned)tag;
-        __builtin_amdgcn_raw_buffer_store_b64(t, r, elem * 8u, 0, 16);  // aux 16 = sc1: write-through, visible to the other XCDs
+        t.y = 0;
     } else {
         const u64 b = (u64)__double_as_longlong(x);
-        u32x4_t t;
         t.x = (unsigned)b;
         t.y = (unsigned)(b >> 32);
-        t.z = (unsigned)tag;
-        t.w = (unsigned)(tag >> 32);
-        __builtin_amdgcn_raw_buffer_store_b128(t, r, elem * 16u, 0, 16);
     }
+    t.z = (unsigned)tag;
+    t.w = (unsigned)(tag >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, elem * 16u, 0, 16);  // aux 16 = sc1: write-through, visible to the other XCDs
 }
 template <class real>
 __device__ __forceinline__ bool get_tagged(__amdgpu_buffer_rsrc_t r, unsigned elem, u64 tag, real* x) {
-    if constexpr (sizeof(real) == 4) {
-        const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, elem * 8u, 0, 16);
-        *x = __uint_as_float(t.x);
-        return t.y == (unsigned)tag;
-    } else {
-        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, elem * 16u, 0, 16);
-        *x = __longlong_as_double((long long)(((u64)t.y << 32) | (u64)t.x));
-        return (((u64)t.w << 32) | (u64)t.z) == tag;
-    }
+    const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, elem * 16u, 0, 16);
+    if constexpr (sizeof(real) == 4) *x = __uint_as_float(t.x);
+    else *x = __longlong_as_double((long long)(((u64)t.y << 32) | (u64)t.x));
+    return (((u64)t.w << 32) | (u64)t.z) == tag;
 }
 template <class real>
-__device__ __forceinline__ u64 pass_tag(u64 ep, int p) {  // never 0 (a fresh buffer is zeroed); fp32: 13 bits of pass, 19 of epoch
-    return sizeof(real) == 4 ? (u64)(unsigned)((unsigned)ep * 8192u + (unsigned)p + 1u) : ((ep << 20) | (u64)(p + 1));
+__device__ __forceinline__ u64 pass_tag(u64 ep, int p) {
+    return (ep << 20) | (u64)(p + 1);
 }
 
 template <class real>
@@ -235,9 +228,9 @@ int relax3d_resident(mgx_ctx* ctx, real* v, const real* f, const int n[3], real 
     const int gy = ceil_div(n[1] - 2, RT), gz = ceil_div(n[2] - 2, RT);
     SweepSync sync;
     MGX_TRY_RET(sweep_state(ctx, &sync));
-    // the exchange buffer: [2][tile][4 faces][RT lines][64] elements of {value, tag}; zeroed when allocated (tag 0 is never
-    // waited for) and, because an fp32 tag has room for 2^19 launch epochs only, again every 2^18 launches
-    const size_t bytes = (size_t)2 * gy * gz * 4 * RT * 64 * 2 * sizeof(real);
+    // the exchange buffer: [2][tile][4 faces][RT lines][64] elements of {value, tag} = 16 bytes; zeroed when allocated (tag 0 is
+    // never waited for)
+    const size_t bytes = (size_t)2 * gy * gz * 4 * RT * 64 * 16;
     if (ctx->resident_bytes < bytes) {
         if (ctx->resident_buf) MGX_HIP(hipFree(ctx->resident_buf));
         ctx->resident_buf = nullptr;
@@ -247,9 +240,8 @@ int relax3d_resident(mgx_ctx* ctx, real* v, const real* f, const int n[3], real 
         MGX_TRY_RET(fill_zero(ctx, ctx->resident_buf, bytes));
     }
     snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_resident_kernel<%s>", sizeof(real) == 8 ? "double" : "float");
-    for (int left = ncycles, first = 1; left > 0; first = 0) {  // a tag has 13 bits for the pass: at most 4000 sweeps per launch
-        const int k = left < 4000 ? left : 4000;
-        if ((++ctx->resident_launches & 0x3ffffu) == 0) MGX_TRY_RET(fill_zero(ctx, ctx->resident_buf, ctx->resident_bytes));
+    for (int left = ncycles, first = 1; left > 0; first = 0) {  // a tag has 20 bits for the pass
+        const int k = left < (1 << 18) ? left : (1 << 18);
         hipLaunchKernelGGL((relax3d_xs_resident_kernel<real>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2,
                            hz2, 2 * k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)bytes, sync);
         left -= k;
