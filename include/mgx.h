@@ -83,6 +83,10 @@ int mgx_ctx_sync(mgx_ctx* ctx);                 /* waits for the compute and com
  * level) has given up on this context -- its workgroups were not resident together; results of that launch are invalid
  * ("relax3d.fused" = 0 / "relax3d.resident" = 0 avoid the kernels).  Meaningful after a synchronisation. */
 int mgx_ctx_check(mgx_ctx* ctx);
+/* allocates now what some kernels would allocate on first use (the progress words and exchange buffer of the kernels whose
+ * workgroups hand data to each other, ~17 MB): the hierarchies call it when they are created, so that their first cycle can
+ * be captured into a HIP graph */
+int mgx_ctx_prepare(mgx_ctx* ctx);
 int mgx_ctx_device(const mgx_ctx* ctx, int* device);
 /* tuning knobs of the x-split smoother kernel (speed only, never results): "relax3d.ty" waves
  * per block and "relax3d.rows" consecutive rows per lane, each in {1,2,4,8}; "relax3d.zchunk"

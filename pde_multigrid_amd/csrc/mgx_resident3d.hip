@@ -223,27 +223,39 @@ bool relax3d_resident_takes(const mgx_ctx* ctx, const int n[3], int ncycles) {
     return ncycles >= ctx->relax_resident_min;
 }
 
+// the exchange buffer at the size of the largest level the kernel takes (as many tiles as CUs): [2][tile][4 faces][RT lines][64]
+// elements of 16 bytes, zeroed (tag 0 is never waited for)
+static int resident_buffer(mgx_ctx* ctx, size_t bytes) {
+    if (ctx->resident_bytes >= bytes) return MGX_OK;
+    if (ctx->resident_buf) MGX_HIP(hipFree(ctx->resident_buf));
+    ctx->resident_buf = nullptr;
+    ctx->resident_bytes = 0;
+    MGX_HIP(hipMalloc(&ctx->resident_buf, bytes));
+    ctx->resident_bytes = bytes;
+    return fill_zero(ctx, ctx->resident_buf, bytes);
+}
+
+// What the kernels with inter-workgroup hand-offs allocate on first use, allocated now: a hierarchy calls this when it is
+// created, so that its first cycle can be captured into a HIP graph (an allocation inside a capture is an error).
+int prepare_handoffs(mgx_ctx* ctx) {
+    SweepSync sync;
+    MGX_TRY_RET(sweep_state(ctx, &sync));
+    const int tiles = ctx->num_cus < SWEEP_MAX_WG ? ctx->num_cus : SWEEP_MAX_WG;
+    return resident_buffer(ctx, (size_t)2 * tiles * 4 * RT * 64 * 16);
+}
+
 template <class real>
 int relax3d_resident(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int ncycles, int zero_start) {
     const int gy = ceil_div(n[1] - 2, RT), gz = ceil_div(n[2] - 2, RT);
     SweepSync sync;
     MGX_TRY_RET(sweep_state(ctx, &sync));
-    // the exchange buffer: [2][tile][4 faces][RT lines][64] elements of {value, tag} = 16 bytes; zeroed when allocated (tag 0 is
-    // never waited for)
     const size_t bytes = (size_t)2 * gy * gz * 4 * RT * 64 * 16;
-    if (ctx->resident_bytes < bytes) {
-        if (ctx->resident_buf) MGX_HIP(hipFree(ctx->resident_buf));
-        ctx->resident_buf = nullptr;
-        ctx->resident_bytes = 0;
-        MGX_HIP(hipMalloc(&ctx->resident_buf, bytes));
-        ctx->resident_bytes = bytes;
-        MGX_TRY_RET(fill_zero(ctx, ctx->resident_buf, bytes));
-    }
+    MGX_TRY_RET(resident_buffer(ctx, bytes));
     snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_resident_kernel<%s>", sizeof(real) == 8 ? "double" : "float");
     for (int left = ncycles, first = 1; left > 0; first = 0) {  // a tag has 20 bits for the pass
         const int k = left < (1 << 18) ? left : (1 << 18);
         hipLaunchKernelGGL((relax3d_xs_resident_kernel<real>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2,
-                           hz2, 2 * k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)bytes, sync);
+                           hz2, 2 * k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)ctx->resident_bytes, sync);
         left -= k;
     }
     return MGX_OK;
@@ -252,3 +264,9 @@ template int relax3d_resident<float>(mgx_ctx*, float*, const float*, const int[3
 template int relax3d_resident<double>(mgx_ctx*, double*, const double*, const int[3], double, double, double, int, int);
 
 }  // namespace mgx
+
+extern "C" int mgx_ctx_prepare(mgx_ctx* ctx) {
+    MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_USE(ctx);
+    return mgx::prepare_handoffs(ctx);
+}

@@ -120,3 +120,23 @@ def test_resident_inside_the_hierarchy(dtype, mode):
         assert bits_equal(got, want)
     finally:
         c.close()
+
+
+def test_resident_inside_a_captured_cycle_on_a_fresh_context():
+    """use_graph with V(3,3) on a context that has run nothing yet: the hierarchy allocates the hand-off buffers when it is
+    created, so the first cycle -- resident Relax launches included -- can be captured; replays advance the launch epoch on
+    the device"""
+    n3 = [65, 65, 65]
+    c = P.Context(0)
+    try:
+        mg = P.MultiGrid3D(c, n3, RG, np.float32)
+        mg.use_graph = True
+        for _ in range(4):
+            mg.VCycle(0, 3, 3)
+        assert c.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+        got = mg.download_v(0)
+        mg.close()
+        c.sync()
+        assert bits_equal(got, O.cycle3d(n3, RG, mode=0, v1=3, v2=3, reps=4, dtype=np.float32))
+    finally:
+        c.close()
