@@ -487,6 +487,9 @@ def main():
             # WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md -- only if they were taken from the kernel that ran
             with open(pmc) as fh:
                 t = json.load(fh)
+            rr = t.get("relax_rr3d_f64_513")
+            if down is not None and rr and rr.get("kernel", "").startswith(down["kernel"]):
+                out["roofline_down"]["traffic"] = rr.get("bytes_per_launch")
             if t.get("kernel_name") == kname:
                 out["roofline"]["traffic"] = t.get("smoother_f64_513_bytes_per_launch")
             else:
