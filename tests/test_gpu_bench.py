@@ -42,5 +42,7 @@ def test_default_line_contract_and_secondary_configs():
     assert out["result_check"]["status"] == "ok"
     assert out["batches"]["min"] <= out["batches"]["median"] == out["ms_per_step"]
     assert 0.3 < out["roofline"]["frac"] < 1.0 and out["roofline"]["bound"] == "hbm"
+    down = out["roofline_down"]  # the fused last black pass + residual + restrict launch of the finest level
+    assert down["kernel"].startswith("relax_rr3d_xs_kernel<double") and 0.2 < down["frac"] < 1.0 and down["avg_launch_us"] > 100
     sec = out["secondary"]
     assert len(sec) == 3 and all(c["result_check"] == "ok" for c in sec.values()), sec
