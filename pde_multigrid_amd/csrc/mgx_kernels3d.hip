@@ -423,6 +423,11 @@ __global__ void __launch_bounds__(64 * WX * WY)
                            int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
                            int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0, int ckmax = 0) {
     constexpr bool CORR = VAR == 2;
+    // VAR == 3: the BLACK pass of the first sweep of a level that counts as all zeros (zero boundary in memory), with the red
+    // pass before it folded in: the caller hands f as `vin`; every other-colour value the pass reads is the red pass's result
+    // relax3d_point(0, ..., 0, f) of the f just loaded (0 on a face of the grid), formed when the load has arrived, and the
+    // red entries of the lane's own pairs are stored next to the black results.  2 instead of 2.5 words per point, one launch.
+    constexpr bool ZERO1 = VAR == 3;
     const double rd = relax3d_rd<real>(hx2, hy2, hz2);  // fp32: the division by multiplication (relax3d_point_rd)
     static_assert(!CORR || R == 2, "the correcting variant is written for 2 rows per lane");
     static_assert(!CORR || (WX * WY >= WY * R / 2 + 2 && WY > 1), "one wave per coarse row under the tile and its rim");
@@ -597,6 +602,25 @@ __global__ void __launch_bounds__(64 * WX * WY)
             MGX_K_STORE(((z0 + 2) >> 1) + 2);
         }
     }
+    // ZERO1: a loaded f value -> the red value at that place (0 on a face: x = 0 / x = sx - 1, a boundary row, a boundary plane)
+    auto zred = [&](real x, bool face) __attribute__((always_inline)) {
+        const real zero = (real)0;
+        return face ? zero : relax3d_point_rd<real>(zero, zero, zero, zero, zero, zero, x, hx2, hy2, hz2, rd);
+    };
+    const bool x0 = j == 0;  // half 0 of the lane's pair is x = 0
+    if constexpr (ZERO1) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = q ^ (r & 1);
+            const bool rowface = y0 + r >= sy - 1;
+            cp[r] = zred(cp[r], rowface || z0 - 1 <= 0 || (qr == 0 && x0));
+            cc[r] = zred(cc[r], rowface || (qr == 1 && x0));
+            cu[r] = zred(cu[r], rowface || z0 + 1 >= szg - 1 || (qr == 0 && x0));
+            xc[r] = zred(xc[r], qr == 1 && j == M - 2);
+        }
+        Nc = zred(Nc, y0 - 1 <= 0 || (q == 0 && x0));
+        Sc = zred(Sc, y0 + R >= sy - 1 || ((q ^ ((R - 1) & 1)) == 0 && x0));
+    }
     publish(z0 & 1, cc);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -606,6 +630,13 @@ __global__ void __launch_bounds__(64 * WX * WY)
         // before the other waves' arithmetic (measured -1.3 % per pass, same-box A/B)
         __builtin_amdgcn_s_setprio(3);
         if (z > z0) store_plane(-1, q ^ 1, op);  // results of plane z-1
+        if constexpr (ZERO1) {  // the red entries of the lane's own pairs at plane z (x = 0 is a boundary point)
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int qo = 1 - (q ^ (r & 1));
+                if (lane_on && (qo | j) && r < nrows) __builtin_nontemporal_store(cc[r], &po[roff[r] + qo * H + j]);
+            }
+        }
         if (more) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -683,6 +714,17 @@ __global__ void __launch_bounds__(64 * WX * WY)
         }
         Nc = Nn;
         Sc = Sn;
+        if constexpr (ZERO1) {  // what arrived in this step was f: the red values at those places (plane z + 2 / the rim of z + 1)
+            const int q1 = q ^ 1;  // the colour's half of row 0 at plane z + 1
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int qn = q1 ^ (r & 1);
+                cu[r] = zred(cu[r], y0 + r >= sy - 1 || z + 2 >= szg - 1 || (qn == 0 && x0));
+                xc[r] = zred(xc[r], qn == 1 && j == M - 2);
+            }
+            Nc = zred(Nc, y0 - 1 <= 0 || (q1 == 0 && x0));
+            Sc = zred(Sc, y0 + R >= sy - 1 || ((q1 ^ ((R - 1) & 1)) == 0 && x0));
+        }
         pv += sxy;
         pf += sxy;
         po += sxy;
@@ -1973,6 +2015,38 @@ static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, in
 #undef MGX_X
 }
 
+// The FIRST SWEEP of a level that counts as all zeros (boundary entries zero in memory) in one launch: the black pass with the
+// red pass folded in (relax3d_xs_pipe_kernel, VAR = 3: f in, red and black out).  Levels and shapes as the automatic choice of
+// relax3d_xs_pass_lds makes them for a colour pass (fp32 levels wide enough for the two-pairs-per-lane kernel: not taken).
+template <class real>
+static bool relax3d_xs_first_sweep_zero(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int sz, real hx2, real hy2, real hz2) {
+    const int M = (sx + 1) / 2, zbeg = 1, zend = sz - 1;
+    if (!ctx->relax_zero_sweep || ctx->relax_lds != -1 || M - 1 < 128 || sy - 2 < 64 || zend - zbeg < 8) return false;
+    if (sizeof(real) == 4 && ctx->relax_v2 && M - 1 >= 256) return false;
+    const bool fnt = (size_t)sx * sy * (size_t)(zend - zbeg) * sizeof(real) > ((size_t)256 << 20);
+    const bool low = sizeof(real) == 8 && sy - 2 <= 256 && !fnt;
+    int zchunk = ctx->relax_zchunk;
+    if (zchunk <= 0) {
+        const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, low ? 8 : 16);
+        const int target = ctx->num_cus * (sizeof(real) == 4 ? 8 : (low ? 2 : 1));
+        const int nchunks = max(1, (target + tiles / 2) / tiles);
+        zchunk = max(8, ceil_div(zend - zbeg, nchunks));
+    }
+    const int gx = ceil_div(M - 1, 128), gy = ceil_div(sy - 2, low ? 8 : 16), gz = ceil_div(zend - zbeg, zchunk);
+    const dim3 grid((unsigned)gx * gy * gz);
+    const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
+    snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,2,%d,2,%s,3>", sizeof(real) == 8 ? "double" : "float",
+             low ? 4 : 8, fnt ? "true" : "false");
+#define MGX_Z1(WYY, F)                                                                                                           \
+    hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, WYY, 2, F, 3>), grid, dim3(64, 2 * WYY, 1), 0, ctx->compute, f, v, f, sx, sy, zbeg, zend, \
+                       hx2, hy2, hz2, 1, zchunk, gx, gy, xcd, (const real*)nullptr, 0, 0, sz, 0)
+    if (low) MGX_Z1(4, false);
+    else if (fnt) MGX_Z1(8, true);
+    else MGX_Z1(8, false);
+#undef MGX_Z1
+    return true;
+}
+
 // one colour pass over the local planes [zbeg, zend) of an x-split array with sx x sy rows
 template <class real>
 static void relax3d_xs_pass(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
@@ -2069,9 +2143,12 @@ int relax3d_from_zero(mgx_ctx* ctx, real* v, const real* f, const int n[3], cons
         MGX_LAUNCH_CHECK();
         return MGX_OK;
     }
-    hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, L>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
-                       ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0, 1);
-    for (int s = 1; s < 2 * ncycles; s++) {
+    int s0 = 1;
+    if (L::xsplit && relax3d_xs_first_sweep_zero<real>(ctx, v, f, n[0], n[1], n[2], hx2, hy2, hz2)) s0 = 2;  // red and black in one launch
+    else
+        hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, L>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
+                           ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0, 1);
+    for (int s = s0; s < 2 * ncycles; s++) {
         if (L::xsplit) relax3d_xs_pass<real>(ctx, v, f, n[0], n[1], 1, n[2] - 1, hx2, hy2, hz2, s & 1);
         else
             hipLaunchKernelGGL((relax3d_colour_kernel<real>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
@@ -2396,9 +2473,13 @@ int smooth_residual_restrict3d_xs(mgx_ctx* ctx, real* v, const real* f, const in
     int s = 0;
     if (from_zero) {
         if (v_rim_is_zero && ctx->relax_zero_first) {  // relax3d_from_zero: the first red pass does not read v
-            hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, XSplit>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2),
-                               blk(), 0, ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0, 1);
-            s = 1;
+            if (2 * ncycles - 1 >= 2 && relax3d_xs_first_sweep_zero<real>(ctx, v, f, n[0], n[1], n[2], hx2, hy2, hz2)) {
+                s = 2;  // the whole first sweep in one launch
+            } else {
+                hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, XSplit>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2),
+                                   blk(), 0, ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0, 1);
+                s = 1;
+            }
         } else {
             MGX_TRY_RET(fill_zero(ctx, v, Geo<XSplit, real>(n[0], n[1]).PL * (size_t)n[2] * sizeof(real)));
         }
@@ -3083,6 +3164,9 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         ctx->cyc2_tail_points = value;
     } else if (!strcmp(name, "relax3d.fused")) {
         ctx->sweep_fused = value ? 1 : 0;  // levels of 513-point rows: one launch per red+black sweep (mgx_sweep3d.hip) or one per colour
+    } else if (!strcmp(name, "relax3d.zero_sweep")) {
+        MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: relax3d.zero_sweep = %d not in {0, 1}", value);
+        ctx->relax_zero_sweep = value;
     } else if (!strcmp(name, "relax3d.resident")) {
         MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: relax3d.resident = %d not in {0, 1}", value);
         ctx->relax_resident = value;
