@@ -99,6 +99,7 @@ int mgx_ctx_device(const mgx_ctx* ctx, int* device);
  * ".pzchunk" coarse planes per run (0 automatic), ".tyw" waves per workgroup, ".cr" coarse rows per lane, ".rows" fine rows
  * per wave of the pipelined kernel (0 = by level size, 2, 4), ".xcd" 0/1/2 XCD-aware block order, ".rcp" 0/1: with
  * power-of-two squared spacings the residual multiplies by the exact reciprocals instead of dividing (same bits);
+ * "relax3d.corr_v2" 0/1: fp32 on wide levels, the correcting red pass with two pairs per lane like the plain passes;
  * "relax3d.zero_sweep" 0/1: relax_from_zero on the pipelined levels runs its first red and black pass as one launch;
  * "relax3d.resident" 0/1 and "relax3d.resident_min" (sweeps per call, default 3): all colour passes of a Relax call on a level
  * of 33 ... 129 points per row in one launch (single-rank contexts only);

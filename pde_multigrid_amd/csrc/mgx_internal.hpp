@@ -37,6 +37,7 @@ struct mgx_ctx {
     int rr_black_waves = 0;  // its waves per workgroup: 0 = by precision, 12, 16
     int relax_zero_first = 1;  // relax_from_zero: the first red pass on a zeroed level does not read v (and nothing is filled)
     int relax_zero_sweep = 1;  // relax_from_zero on the pipelined levels: the first red AND black pass in one launch (f in, both colours out)
+    int corr_v2 = 1;       // fp32 on wide levels: the correcting red pass with two pairs per lane too (relax3d_xs_pipe_v2_kernel, VAR = 2)
     int relax_v2 = 1;      // fp32 smoother on wide levels: two x-pairs per lane (8-byte loads)
     int corr_fuse = 1;     // interpolate_correct_relax3d: the first red pass applies the coarse-grid correction on the fly
     int cyc2_tile = 0;     // tile edge of the cache-resident 2D cycle kernels: 0 = by level size, 16 / 32 / 64

@@ -750,14 +750,22 @@ struct Vec2T {
     typedef real type __attribute__((ext_vector_type(2)));
 };
 
-template <class real, int WX, int WY, int R, bool FNT = false>
+// VAR = 2: the correcting red pass of relax3d_xs_pipe_kernel (the black values read through v + Interpolate(coarse), coarse
+// planes staged in LDS, the set P corrected in place beforehand) for two pairs per lane: the staged tile is 128 WX + 2 coarse
+// columns wide, a lane interpolates for both of its pairs.
+template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0>
 __global__ void __launch_bounds__(64 * WX * WY)
     relax3d_xs_pipe_v2_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                               int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
-                              int xcd_mode) {
+                              int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0, int ckmax = 0) {
     typedef typename Vec2T<real>::type vec2;
+    constexpr bool CORR = VAR == 2;
+    static_assert(!CORR || R == 2, "the correcting variant is written for 2 rows per lane");
+    static_assert(!CORR || (WX * WY >= WY * R / 2 + 1 && WY > 1), "one wave per coarse row under the tile and its rim");
+    constexpr int KR = WY * R / 2 + 1, NK = 2 * WX, KC = 64 * NK + 2;  // coarse rows / columns staged per plane
     __shared__ vec2 ey[2][WY][WX][2][64];
     __shared__ real ex[2][WY][WX][2][R];  // [lane 0's element 0 / lane 63's element 1]
+    __shared__ real sK[CORR ? 3 : 1][CORR ? KR : 1][CORR ? KC : 1];
     const Geo<XSplit, real> g(sx, sy);
     const int H = g.H;
     const int M = (sx + 1) >> 1;  // M - 1 pairs hold an interior point; M - 1 is even (sx = 2^k + 1 >= 5)
@@ -795,6 +803,57 @@ __global__ void __launch_bounds__(64 * WX * WY)
     vec2 cp[R], cc[R], cu[R], cn[R], fc[R], fn[R], oc[R], op[R];
     real xc[R], xn[R];
     vec2 Nc = {0, 0}, Sc = {0, 0}, Nn = {0, 0}, Sn = {0, 0};
+    // CORR: as in relax3d_xs_pipe_kernel -- coarse geometry, this thread's share of the staging of one coarse plane (wave
+    // w < KR: row w, columns lane + 64 a and, lanes 0 and 1, the last two), the lane's first coarse cell in the staged tile
+    const Geo<XSplit, real> gcs(CORR ? cx : 3, CORR ? cy : 3);
+    const int CH = gcs.H, CP = gcs.P;
+    const size_t CPL = gcs.PL;
+    const int cy0t = CORR ? (by * WY * R) / 2 : 0, cx0t = bx * WX * 128;
+    int kg[NK + 1];
+    const bool kload = CORR && w < KR, klast = kload && lane < 2;
+#pragma unroll
+    for (int a = 0; a <= NK; a++)
+        kg[a] = CORR ? min(cy0t + w, cy - 1) * CP + XSplit::pos(min(max(cx0t - 1 + lane + 64 * a, 0), cx - 1), CH) : 0;
+    real kt[NK + 1];
+#pragma unroll
+    for (int a = 0; a <= NK; a++) kt[a] = 0;
+    const int kmy = wy * (R / 2) * KC + wx * 128 + 2 * lane + 1;  // coarse cell (column j0, row (y0 - 1) / 2); the second pair's: + 1
+    bool own0[R], own1[R];  // does the entry of pair j0 / j0 + 1 in row r get its correction on the fly (not in the set P)?
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const bool rowP = (wy == 0 && r == 0) || (wy == WY - 1 && r == R - 1);
+        own0[r] = CORR && lane_on && !rowP && !(j0 > 0 && j0 % (128 * WX) == 0) && y0 + r <= sy - 2;
+        own1[r] = CORR && lane_on && !rowP && (j0 + 1) % (128 * WX) != 128 * WX - 1 && y0 + r <= sy - 2;
+    }
+#define MGX_K2_REQUEST(plane)                                                                   \
+    do {                                                                                        \
+        if (kload) {                                                                            \
+            const real* c_ = coarse + (size_t)(plane) * CPL;                                    \
+            _Pragma("unroll") for (int a = 0; a < NK; a++) kt[a] = c_[kg[a]];                   \
+            if (klast) kt[NK] = c_[kg[NK]];                                                     \
+        }                                                                                       \
+    } while (0)
+#define MGX_K2_STORE(plane)                                                                     \
+    do {                                                                                        \
+        if (kload) {                                                                            \
+            real* d_ = &sK[(plane) % 3][w][lane];                                               \
+            _Pragma("unroll") for (int a = 0; a < NK; a++) d_[64 * a] = kt[a];                  \
+            if (klast) d_[64 * NK] = kt[NK];                                                    \
+        }                                                                                       \
+    } while (0)
+#define MGX_CORR_PAIR2(kofs, px0, zz, e0, e1)                                                                       \
+    do {                                                                                                            \
+        const real* k0_ = &sK[0][0][0] + ((zz) >> 1) % 3 * (KR * KC) + (kofs);                                      \
+        const real* k1_ = &sK[0][0][0] + (((zz) >> 1) + 1) % 3 * (KR * KC) + (kofs);                                \
+        auto g0_ = [&](int dx, int dy, int dz) { return (dz ? k1_ : k0_)[dy * KC + dx]; };                          \
+        auto g1_ = [&](int dx, int dy, int dz) { return (dz ? k1_ : k0_)[KC + dy * KC + dx]; };                     \
+        switch ((px0) * 2 + ((zz) & 1)) {                                                                           \
+            case 0: e0 = interpolate3d_point<real>(0, 1, 0, g0_); e1 = interpolate3d_point<real>(1, 0, 0, g1_); break; \
+            case 1: e0 = interpolate3d_point<real>(0, 1, 1, g0_); e1 = interpolate3d_point<real>(1, 0, 1, g1_); break; \
+            case 2: e0 = interpolate3d_point<real>(1, 1, 0, g0_); e1 = interpolate3d_point<real>(0, 0, 0, g1_); break; \
+            default: e0 = interpolate3d_point<real>(1, 1, 1, g0_); e1 = interpolate3d_point<real>(0, 0, 1, g1_); break; \
+        }                                                                                                           \
+    } while (0)
 #define MGX_LD2(p, i) (*(const vec2*)&(p)[(i)])
 #define MGX_LOAD_RIM2(dz, qq, X, Nv, Sv)                                                       \
     do {                                                                                       \
@@ -846,6 +905,32 @@ __global__ void __launch_bounds__(64 * WX * WY)
         cn[r] = fn[r] = oc[r] = vec2{0, 0};
     }
     MGX_LOAD_RIM2(0, q, xc, Nc, Sc);
+    if constexpr (CORR) {
+        // own entries of the planes z0-1, z0, z0+1: the correction straight from the coarse array, once per run of planes
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int qr = q ^ (r & 1), y = y0 + r;
+            if (own0[r]) {
+                if (z0 - 1 >= 1 && (qr | j0)) cp[r].x = cp[r].x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + qr, y, z0 - 1);
+                if ((1 - qr) | j0) cc[r].x = cc[r].x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + 1 - qr, y, z0);
+                if (z0 + 1 <= szg - 2 && (qr | j0)) cu[r].x = cu[r].x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + qr, y, z0 + 1);
+            }
+            if (own1[r]) {
+                if (z0 - 1 >= 1) cp[r].y = cp[r].y + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + qr, y, z0 - 1);
+                cc[r].y = cc[r].y + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + 1 - qr, y, z0);
+                if (z0 + 1 <= szg - 2) cu[r].y = cu[r].y + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + qr, y, z0 + 1);
+            }
+        }
+        // the coarse planes under the arrivals of the first three steps (the loop's requests start with the fourth)
+        MGX_K2_REQUEST(min((z0 + 2) >> 1, ckmax));
+        MGX_K2_STORE((z0 + 2) >> 1);
+        MGX_K2_REQUEST(min(((z0 + 2) >> 1) + 1, ckmax));
+        MGX_K2_STORE(((z0 + 2) >> 1) + 1);
+        if (z0 & 1) {
+            MGX_K2_REQUEST(min(((z0 + 2) >> 1) + 2, ckmax));
+            MGX_K2_STORE(((z0 + 2) >> 1) + 2);
+        }
+    }
     publish(z0 & 1, cc);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -860,6 +945,9 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 fn[r] = FNT ? __builtin_nontemporal_load((const vec2*)&pf[roff[r] + sxy + qn * H + j0]) : MGX_LD2(pf, roff[r] + sxy + qn * H + j0);
             }
             MGX_LOAD_RIM2(1, q ^ 1, xn, Nn, Sn);
+            if constexpr (CORR) {
+                if (!(z & 1) && z + 4 < z1) MGX_K2_REQUEST(min((z >> 1) + 3, ckmax));  // the LAST loads of the step (see relax3d_xs_pipe_kernel)
+            }
             publish((z + 1) & 1, cu);
         }
         const int slot = z & 1;
@@ -889,16 +977,45 @@ __global__ void __launch_bounds__(64 * WX * WY)
             oc[r].x = relax3d_point_rd<real>(W0, E0, N.x, S.x, cp[r].x, cu[r].x, fc[r].x, hx2, hy2, hz2, rd);
             oc[r].y = relax3d_point_rd<real>(W1, E1, N.y, S.y, cp[r].y, cu[r].y, fc[r].y, hx2, hy2, hz2, rd);
         }
+        real en0[R], en1[R];  // CORR: the corrections of the entries that are on their way (plane z + 2) ...
+        bool dc0[R], dc1[R];  // ... if they get one
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            en0[r] = en1[r] = 0;
+            dc0[r] = dc1[r] = false;
+        }
+        if constexpr (CORR) {
+            if (more) {
+                MGX_CORR_PAIR2(kmy, q ^ 1, z + 2, en0[0], en0[1]);
+                MGX_CORR_PAIR2(kmy + 1, q ^ 1, z + 2, en1[0], en1[1]);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    dc0[r] = own0[r] && z + 2 <= szg - 2 && ((q ^ 1 ^ (r & 1)) | j0);
+                    dc1[r] = own1[r] && z + 2 <= szg - 2;
+                }
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (CORR && kload && more && !(z & 1) && z + 4 < z1) {
+            // the staging loads issued last in this step stay in flight (loads return in order: at most NK + 1 outstanding
+            // operations means everything issued before them has arrived); they are stored a step later
+            if constexpr (NK == 4) __builtin_amdgcn_s_waitcnt(0x0F75);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) {
             cp[r] = cc[r];
             cc[r] = cu[r];
-            cu[r] = cn[r];
+            cu[r].x = dc0[r] ? cn[r].x + en0[r] : cn[r].x;
+            cu[r].y = dc1[r] ? cn[r].y + en1[r] : cn[r].y;
             fc[r] = fn[r];
             xc[r] = xn[r];
             op[r] = oc[r];
+        }
+        if constexpr (CORR) {
+            if ((z & 1) && z > z0 && z + 3 < z1) MGX_K2_STORE(((z - 1) >> 1) + 3);  // requested in step z - 1
         }
         Nc = Nn;
         Sc = Sn;
@@ -910,6 +1027,9 @@ __global__ void __launch_bounds__(64 * WX * WY)
     store_plane(-1, q ^ 1, op);
 #undef MGX_LOAD_RIM2
 #undef MGX_LD2
+#undef MGX_K2_REQUEST
+#undef MGX_K2_STORE
+#undef MGX_CORR_PAIR2
 }
 
 // ------------------------------------------------------------------ relax, whole small level in one workgroup
@@ -2677,10 +2797,18 @@ static bool corr_fused_takes(const mgx_ctx* ctx, int sx, int sy, int sz_global, 
 // the set P (tile-edge cells of that pass) corrected in place: the coarse cells covering the GLOBAL fine planes [zmin, zmax),
 // which are the only ones written.  v / coarse_v are local arrays starting at the global planes fzoff / czoff; every coarse
 // plane a written fine plane interpolates from must exist locally.
+// pairs per tile of the correcting red pass on a level of sx-point rows
+template <class real>
+static int corr_tile_pairs(const mgx_ctx* ctx, int sx) {
+    return sizeof(real) == 4 && ctx->relax_v2 && ctx->corr_v2 && (sx + 1) / 2 - 1 >= 256 ? 256 : 128;
+}
 template <class real>
 static void corr_pset_launch(mgx_ctx* ctx, real* v, int sx, int sy, int fzoff, const real* coarse_v, const int cn[3], int czoff, int zmin,
                              int zmax) {
-    constexpr int PW = 128, PH = 8;  // the tile of relax3d_xs_pipe_kernel<real, 2, 8, 2>: 128 pairs x 16 rows
+    // the tile of the correcting pass: 128 pairs x 16 rows (relax3d_xs_pipe_kernel<real, 2, 8, 2>) or, fp32 on wide levels,
+    // 256 pairs x 16 rows (relax3d_xs_pipe_v2_kernel<real, 2, 8, 2>)
+    const int PW = corr_tile_pairs<real>(ctx, sx);
+    constexpr int PH = 8;
     const int M = (sx + 1) / 2;
     const int pzbeg = zmin / 2, pzend = (zmax - 1) / 2 + 1;
     if (pzend <= pzbeg) return;
@@ -2701,6 +2829,25 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
                             const real* coarse_sh, int cx, int cy, int szl, int ckmax) {
     const int M = (sx + 1) / 2;
     int zchunk = ctx->relax_zchunk;
+    if (corr_tile_pairs<real>(ctx, sx) == 256) {  // fp32, wide level: two pairs per lane
+        if (zchunk <= 0) {
+            const int tiles = ceil_div(M - 1, 256) * ceil_div(sy - 2, 16);
+            const int nchunks = max(1, (ctx->num_cus + tiles / 2) / tiles);
+            zchunk = max(8, ceil_div(ze - zb, nchunks));
+        }
+        const int gx2 = ceil_div(M - 1, 256), gy2 = ceil_div(sy - 2, 16), gz2 = ceil_div(ze - zb, zchunk);
+        const bool fnt2 = (size_t)sx * sy * (size_t)(ze - zb) * sizeof(real) > ((size_t)256 << 20);
+        snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_v2_kernel<%s,2,8,2,%s,2>", sizeof(real) == 8 ? "double" : "float",
+                 fnt2 ? "true" : "false");
+        const dim3 grid2((unsigned)gx2 * gy2 * gz2);
+        if (fnt2)
+            hipLaunchKernelGGL((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, true, 2>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx,
+                               sy, zb, ze, hx2, hy2, hz2, colour, zchunk, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
+        else
+            hipLaunchKernelGGL((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, false, 2>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx,
+                               sy, zb, ze, hx2, hy2, hz2, colour, zchunk, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
+        return;
+    }
     if (zchunk <= 0) {  // one resident round of 16-wave workgroups as in relax3d_xs_pass_lds
         const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, 16);
         const int target = ctx->num_cus * (sizeof(real) == 4 ? 8 : 1);
@@ -3164,6 +3311,9 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         ctx->cyc2_tail_points = value;
     } else if (!strcmp(name, "relax3d.fused")) {
         ctx->sweep_fused = value ? 1 : 0;  // levels of 513-point rows: one launch per red+black sweep (mgx_sweep3d.hip) or one per colour
+    } else if (!strcmp(name, "relax3d.corr_v2")) {
+        MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: relax3d.corr_v2 = %d not in {0, 1}", value);
+        ctx->corr_v2 = value;
     } else if (!strcmp(name, "relax3d.zero_sweep")) {
         MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: relax3d.zero_sweep = %d not in {0, 1}", value);
         ctx->relax_zero_sweep = value;
