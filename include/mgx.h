@@ -104,7 +104,7 @@ int mgx_ctx_device(const mgx_ctx* ctx, int* device);
  * "relax3d.resident" 0/1 and "relax3d.resident_min" (sweeps per call, default 3): all colour passes of a Relax call on a level
  * of 33 ... 129 points per row in one launch (single-rank contexts only);
  * "rr3d.black" 0 / 1 / 2: the last black pass of the pre-smoothing inside the residual+restrict launch -- off / on the
- * HBM-bound levels / wherever the geometry allows (tests), "rr3d.black_waves" 0 (by precision), 12, 16 waves per workgroup.
+ * HBM-bound levels / wherever the geometry allows (tests), "rr3d.black_waves" 0 (by precision), 8 (two workgroups per CU), 12, 16 waves per workgroup.
  * Unknown names and out-of-range values are rejected (MGX_ERR_INVALID). */
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value);
 /* name (kernel<template arguments>) of the smoother kernel the most recent 3D x-split colour pass launched; "" if none.
@@ -113,6 +113,9 @@ const char* mgx_ctx_last_relax_kernel(const mgx_ctx* ctx);
 /* name of the kernel that ran the last black pass together with residual + restrict in the most recent
  * mgx3dxs_smooth_residual_restrict_* call; "" when that call ran the operators one after the other */
 const char* mgx_ctx_last_rr_kernel(const mgx_ctx* ctx);
+/* name of the kernel that ran the correcting red pass (the correction read on the fly) in the most recent
+ * mgx3dxs_interpolate_correct_relax_* call; "" when that call corrected in a pass of its own */
+const char* mgx_ctx_last_corr_kernel(const mgx_ctx* ctx);
 /* raw hipStream_t of the compute stream (for callers that bring their own HIP code) */
 int mgx_ctx_stream(const mgx_ctx* ctx, void** hip_stream);
 

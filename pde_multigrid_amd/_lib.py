@@ -39,6 +39,7 @@ lib.mgx_last_error.restype = C.c_char_p
 lib.mgx_version.restype = C.c_char_p
 lib.mgx_ctx_last_relax_kernel.restype = C.c_char_p
 lib.mgx_ctx_last_rr_kernel.restype = C.c_char_p
+lib.mgx_ctx_last_corr_kernel.restype = C.c_char_p
 
 
 def status_string(status):

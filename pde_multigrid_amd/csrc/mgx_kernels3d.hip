@@ -1038,6 +1038,55 @@ __global__ void __launch_bounds__(64 * WX * WY)
 // in fp64) and runs all `ncycles` red-black sweeps with a barrier between colour passes.  Same per-point
 // expression, same colour order: bit-identical to the multi-launch path.
 constexpr int SMALL_MAX = 17;
+// Who updates which point in a colour pass.  With point t owned by thread t % 1024 the colours alternate from lane to lane
+// (every extent is odd), so each pass ran all five slots of a thread with half the lanes off.  Instead slot k of colour c of
+// thread t is the (t + 1024 k)-th INTERIOR point of that colour in x-fastest order: two slots per colour cover 17^3 and all
+// lanes of a slot work.  The interior extents are odd too, so the m-th interior point has colour (m + 1) & 1.
+constexpr int SMALL_CS = (((SMALL_MAX - 2) * (SMALL_MAX - 2) * (SMALL_MAX - 2) + 1) / 2 + 1023) / 1024;  // slots per colour
+struct SmallOwn {
+    int at[2][SMALL_CS];  // index of the point in the level's LDS array (natural order), -1 = no point
+};
+__device__ __forceinline__ void small_own(SmallOwn& o, int sx, int sy, int sz) {
+    const int mx = sx - 2, mxy = mx * (sy - 2), mn = mxy * (sz - 2), sxy = sx * sy;
+    const SmallDiv dxy(mxy), dx(mx);
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int k = 0; k < SMALL_CS; k++) {
+            const int m = 2 * ((int)threadIdx.x + 1024 * k) + ((c + 1) & 1);
+            o.at[c][k] = -1;
+            if (m < mn) {
+                const int iz = dxy(m), iy = dx(m - iz * mxy), ix = m - iz * mxy - iy * mx;
+                o.at[c][k] = (iz + 1) * sxy + (iy + 1) * sx + ix + 1;
+            }
+        }
+}
+// `ncycles` red-black sweeps of a level held in LDS (sv, sf in natural order); ends with a barrier.  f of the owned points
+// stays in registers; the fp32 quotient is formed as in relax3d_point_rd (same bits as the division).
+template <class real>
+__device__ __forceinline__ void small_relax3(real* sv, const real* sf, int sx, int sxy, const SmallOwn& o, real hx2, real hy2, real hz2,
+                                             int ncycles) {
+    real fv[2][SMALL_CS];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int k = 0; k < SMALL_CS; k++) fv[c][k] = o.at[c][k] >= 0 ? sf[o.at[c][k]] : (real)0;
+    const double rd = relax3d_rd<real>(hx2, hy2, hz2);
+    auto pass = [&](const int (&at)[SMALL_CS], const real (&ff)[SMALL_CS]) {
+#pragma unroll
+        for (int k = 0; k < SMALL_CS; k++) {
+            const int t = at[k];
+            if (t >= 0)
+                sv[t] = relax3d_point_rd<real>(sv[t - 1], sv[t + 1], sv[t - sx], sv[t + sx], sv[t - sxy], sv[t + sxy], ff[k], hx2, hy2, hz2, rd);
+        }
+        __syncthreads();
+    };
+    for (int c = 0; c < ncycles; c++) {
+        pass(o.at[0], fv[0]);  // red = 0 first (N3/MultiGrid3D.cpp:515)
+        pass(o.at[1], fv[1]);  // then black (:544)
+    }
+}
+
 template <class real, class L>
 __global__ void __launch_bounds__(1024) relax3d_small_kernel(real* __restrict__ v, const real* __restrict__ f, int sx, int sy,
                                                              int sz, real hx2, real hy2, real hz2, int ncycles) {
@@ -1047,36 +1096,27 @@ __global__ void __launch_bounds__(1024) relax3d_small_kernel(real* __restrict__ 
     const Geo<L, real> g(sx, sy);
     const int n = sx * sy * sz, sxy = sx * sy;
     size_t gidx[PT];
-    int kind[PT];  // -1 = not a point / boundary, else the colour of the interior point
+    bool inner[PT];  // an interior point (written back)
 #pragma unroll
     for (int k = 0; k < PT; k++) {
         const int t = threadIdx.x + k * 1024;
-        kind[k] = -1;
+        inner[k] = false;
         gidx[k] = 0;
         if (t < n) {
             const int z = SmallDiv(sxy)(t), y = SmallDiv(sx)(t - z * sxy), x = t - z * sxy - y * sx;
             gidx[k] = g.row(y, z) + g.pos(x);
             sv[t] = v[gidx[k]];
             sf[t] = f[gidx[k]];
-            if (x > 0 && x < sx - 1 && y > 0 && y < sy - 1 && z > 0 && z < sz - 1) kind[k] = (x + y + z) & 1;
+            inner[k] = x > 0 && x < sx - 1 && y > 0 && y < sy - 1 && z > 0 && z < sz - 1;
         }
     }
+    SmallOwn own;
+    small_own(own, sx, sy, sz);
     __syncthreads();
-    for (int c = 0; c < 2 * ncycles; c++) {
-        const int colour = c & 1;  // red = 0 first (N3/MultiGrid3D.cpp:515), then black (:544)
-#pragma unroll
-        for (int k = 0; k < PT; k++) {
-            if (kind[k] == colour) {
-                const int t = threadIdx.x + k * 1024;
-                sv[t] = relax3d_point<real>(sv[t - 1], sv[t + 1], sv[t - sx], sv[t + sx], sv[t - sxy], sv[t + sxy], sf[t], hx2,
-                                            hy2, hz2);
-            }
-        }
-        __syncthreads();
-    }
+    small_relax3<real>(sv, sf, sx, sxy, own, hx2, hy2, hz2, ncycles);
 #pragma unroll
     for (int k = 0; k < PT; k++)
-        if (kind[k] >= 0) v[gidx[k]] = sv[threadIdx.x + k * 1024];
+        if (inner[k]) v[gidx[k]] = sv[threadIdx.x + k * 1024];
 }
 
 // ------------------------------------------------------------------ the whole cycle below 17^3 in one workgroup
@@ -1095,21 +1135,6 @@ struct Tail3 {
     real* f[TAIL3_MAXLEV];
     real hx[TAIL3_MAXLEV], hy[TAIL3_MAXLEV], hz[TAIL3_MAXLEV];
 };
-
-template <class real>
-__device__ __forceinline__ void tail_relax3(real* sv, const real* sf, int sx, int sxy, const int (&kind)[TAIL3_PT], real hx2, real hy2,
-                                            real hz2, int ncycles) {
-    for (int c = 0; c < 2 * ncycles; c++) {
-        const int colour = c & 1;  // red = 0 first (N3/MultiGrid3D.cpp:515), then black (:544)
-#pragma unroll
-        for (int k = 0; k < TAIL3_PT; k++)
-            if (kind[k] == colour) {
-                const int t = threadIdx.x + k * 1024;
-                sv[t] = relax3d_point<real>(sv[t - 1], sv[t + 1], sv[t - sx], sv[t + sx], sv[t - sxy], sv[t + sxy], sf[t], hx2, hy2, hz2);
-            }
-        __syncthreads();
-    }
-}
 
 template <class real, class L>
 __global__ void __launch_bounds__(1024) cycle3d_tail_kernel(Tail3<real> T, int v1, int v2, int mode, int top_zero) {
@@ -1158,12 +1183,14 @@ __global__ void __launch_bounds__(1024) cycle3d_tail_kernel(Tail3<real> T, int v
         real* sf = base + offf[l];
         const int sx = T.sx[l], sy = T.sy[l], sz = T.sz[l], sxy = sx * sy, n = sxy * sz;
         const real hx2 = T.hx[l] * T.hx[l], hy2 = T.hy[l] * T.hy[l], hz2 = T.hz[l] * T.hz[l];  // :498-500
-        classify(sx, sy, sz);
-        tail_relax3<real>(sv, sf, sx, sxy, kind, hx2, hy2, hz2, v1);  // :626
+        SmallOwn own;
+        small_own(own, sx, sy, sz);
+        small_relax3<real>(sv, sf, sx, sxy, own, hx2, hy2, hz2, v1);  // :626
         if (l == last) {
-            tail_relax3<real>(sv, sf, sx, sxy, kind, hx2, hy2, hz2, v2);  // :645 on the coarsest level
+            small_relax3<real>(sv, sf, sx, sxy, own, hx2, hy2, hz2, v2);  // :645 on the coarsest level
             break;
         }
+        classify(sx, sy, sz);
 #pragma unroll
         for (int k = 0; k < TAIL3_PT; k++) {  // CalculateResidual (:723), 0 on the boundary (:704-705)
             const int t = threadIdx.x + k * 1024;
@@ -1217,7 +1244,9 @@ __global__ void __launch_bounds__(1024) cycle3d_tail_kernel(Tail3<real> T, int v
                 sv[t] = sv[t] + e;
             }
         __syncthreads();
-        tail_relax3<real>(sv, sf, sx, sxy, kind, hx2, hy2, hz2, v2);  // :645
+        SmallOwn own;
+        small_own(own, sx, sy, sz);
+        small_relax3<real>(sv, sf, sx, sxy, own, hx2, hy2, hz2, v2);  // :645
     }
     // what the launch-per-operator path leaves behind: v of every level, the restricted residual in f below the top
     for (int l = 0; l <= last; l++) {
@@ -2839,6 +2868,7 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
         const bool fnt2 = (size_t)sx * sy * (size_t)(ze - zb) * sizeof(real) > ((size_t)256 << 20);
         snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_v2_kernel<%s,2,8,2,%s,2>", sizeof(real) == 8 ? "double" : "float",
                  fnt2 ? "true" : "false");
+        memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
         const dim3 grid2((unsigned)gx2 * gy2 * gz2);
         if (fnt2)
             hipLaunchKernelGGL((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, true, 2>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx,
@@ -2860,6 +2890,7 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
     const bool fnt = (size_t)sx * sy * (size_t)(ze - zb) * sizeof(real) > ((size_t)256 << 20);
     snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,2,8,2,%s,2>", sizeof(real) == 8 ? "double" : "float",
              fnt ? "true" : "false");
+    memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
     if (fnt)
         hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 8, 2, true, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
                            hx2, hy2, hz2, colour, zchunk, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax);
@@ -2888,6 +2919,7 @@ int interpolate_correct_relax3d_xs(mgx_ctx* ctx, real* v, const real* f, const i
     st = check_coarse3(n, cn, "interpolate_correct_relax3d");
     if (st) return st;
     MGX_REQUIRE(ncycles >= 1, MGX_ERR_INVALID, "interpolate_correct_relax3d: ncycles = %d < 1 (use interpolate_correct)", ncycles);
+    ctx->last_corr_kernel[0] = 0;
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // :498-500
     const int sx = n[0], sy = n[1], sz = n[2], zb = 1, ze = sz - 1;
     if (!corr_fused_takes(ctx, sx, sy, sz, ze - zb)) {
@@ -3243,6 +3275,7 @@ MGX_DEFINE_MISC3D(f64, double)
 
 const char* mgx_ctx_last_relax_kernel(const mgx_ctx* ctx) { return ctx ? ctx->last_relax_kernel : ""; }
 const char* mgx_ctx_last_rr_kernel(const mgx_ctx* ctx) { return ctx ? ctx->last_rr_kernel : ""; }
+const char* mgx_ctx_last_corr_kernel(const mgx_ctx* ctx) { return ctx ? ctx->last_corr_kernel : ""; }
 
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     MGX_REQUIRE(ctx && name, MGX_ERR_INVALID, "set_param: NULL argument");
@@ -3327,7 +3360,7 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "set_param: rr3d.black = %d not in {0, 1, 2}", value);
         ctx->rr_black = value;
     } else if (!strcmp(name, "rr3d.black_waves")) {
-        MGX_REQUIRE(value == 0 || value == 12 || value == 16, MGX_ERR_INVALID, "set_param: rr3d.black_waves = %d not in {0, 12, 16}", value);
+        MGX_REQUIRE(value == 0 || value == 8 || value == 12 || value == 16, MGX_ERR_INVALID, "set_param: rr3d.black_waves = %d not in {0, 8, 12, 16}", value);
         ctx->rr_black_waves = value;
     } else if (!strcmp(name, "rr3d.black_abl")) {
 #ifdef MGX_DIAGNOSTICS

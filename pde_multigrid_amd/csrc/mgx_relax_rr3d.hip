@@ -59,7 +59,7 @@ __device__ __forceinline__ void buf_store_nt(real x, __amdgpu_buffer_rsrc_t r, u
 // DBG (diagnostic builds only): `abl` switches parts of an iteration off for timing (WRONG results): 1 no loads, 2 no stores of
 // v, 4 no relax arithmetic, 8 no residual arithmetic, 16 no barrier, 32 no sub-sums / coarse rows.
 template <class real, int MODE, int TYW, int DBG = 0>
-__global__ void __launch_bounds__(64 * TYW)
+__global__ void __launch_bounds__(64 * TYW, 4)  // four waves per SIMD (128 VGPRs) whatever the shape: 8-wave workgroups run two to a CU
     relax_rr3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy, int sz,
                          real hx2, real hy2, real hz2, real qx, real qy, real qz, real* __restrict__ coarse, int cx, int cy, int cz,
                          int pzchunk, int gx, int gy, int xcd_mode, int pzbeg, int pzend, int fzoff, int czoff, int abl = 0) {
@@ -314,7 +314,8 @@ bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], 
     // n, cn: GLOBAL sizes; v / f start at global fine plane fzoff, coarse_f at global coarse plane czoff; the launch relaxes
     // the black points of the fine planes [2 pzbeg - 1, 2 pzend - 1] and forms the coarse planes [pzbeg, pzend)
     if (!relax_rr3d_xs_takes(ctx, n, cn, sizeof(real)) || pzbeg < 1 || pzend > cn[2] - 1 || pzend <= pzbeg) return false;
-    const int T = ctx->rr_black_waves == 12 ? 12 : 16;
+    const int T = ctx->rr_black_waves == 12 ? 12 : ctx->rr_black_waves == 8 ? 8 : 16;
+    const int wg_per_cu = T == 8 ? 2 : 1;
     const int gx = ceil_div(cn[0] - 2, 61), gy = ceil_div(cn[1] - 2, T - 2);
     const int tiles = gx * gy, planes = pzend - pzbeg;
     int pzc = ctx->rr_pzchunk;
@@ -324,7 +325,7 @@ bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], 
         int nchunks = 1;
         double best = 0;
         for (int c = 1; c <= 16 && planes / c >= 8; c++) {
-            const long long wgs = (long long)tiles * c, cap = ctx->num_cus;
+            const long long wgs = (long long)tiles * c, cap = (long long)ctx->num_cus * wg_per_cu;
             const double eff = (double)wgs / (double)(((wgs + cap - 1) / cap) * cap) * (double)planes / (double)(planes + 2 * c);
             if (eff > best + 1e-9) { best = eff; nchunks = c; }
             if (eff >= 0.9) break;
@@ -349,7 +350,7 @@ bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], 
 #endif
 #define MGX_BRR_W(M)                              \
     do {                                          \
-        if (T == 16) MGX_BRR(M, 16); else MGX_BRR(M, 12); \
+        if (T == 16) MGX_BRR(M, 16); else if (T == 12) MGX_BRR(M, 12); else MGX_BRR(M, 8); \
     } while (0)
     if (mode == MGX_RESIDUAL_REF_COMPAT) {
         if (rcp) MGX_BRR_W(2); else MGX_BRR_W(0);

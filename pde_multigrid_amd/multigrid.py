@@ -88,6 +88,10 @@ class Context:
         """the fused black pass + residual + restrict kernel of the most recent smooth_residual_restrict call ("" = not fused)"""
         return lib.mgx_ctx_last_rr_kernel(self._h).decode()
 
+    def last_corr_kernel(self):
+        """the correcting red pass of the most recent interpolate_correct_relax call ("" = the correction was a pass of its own)"""
+        return lib.mgx_ctx_last_corr_kernel(self._h).decode()
+
     def set_param(self, name, value):
         check(lib.mgx_ctx_set_param(self._h, name.encode(), C.c_int(int(value))))
 

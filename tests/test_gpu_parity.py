@@ -281,6 +281,30 @@ def test_3d_xsplit_interpolate_correct_relax_fused(ctx, dtype, n3):
         ctx.set_param("relax3d.zchunk", 0)
 
 
+@pytest.mark.parametrize("n3", [(513, 129, 17), (513, 257, 33), (1025, 129, 17), (2049, 129, 17)])
+def test_3d_xsplit_correcting_pass_two_pairs_per_lane(ctx, n3):
+    """fp32, rows of >= 513 points: the correcting red pass runs as relax3d_xs_pipe_v2_kernel<float,...,2> (tiles of 256
+    pairs: set P has a cell column every 256 pairs, a lane interpolates for both of its pairs); "relax3d.corr_v2" = 0 is the
+    one-pair-per-lane kernel.  Both against the oracle"""
+    rg = [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(sum(n3) + 1)
+    cn = P.coarse_size(n3)
+    v, f = (rng.uniform(-1, 1, O.shape(n3)).astype(np.float32) for _ in range(2))
+    c = rng.uniform(-1, 1, O.shape(cn)).astype(np.float32)
+    corrected = O.correct3d(n3, v, O.interpolate3d(n3, np.zeros(O.shape(n3), np.float32), c, dtype=np.float32), dtype=np.float32)
+    want = O.relax3d(n3, rg, corrected, f, 1, dtype=np.float32)
+    try:
+        for on, name in ((1, "relax3d_xs_pipe_v2_kernel<float"), (0, "relax3d_xs_pipe_kernel<float")):
+            ctx.set_param("relax3d.corr_v2", on)
+            for zchunk in (0, 2, 5):
+                ctx.set_param("relax3d.zchunk", zchunk)
+                assert bits_equal(P.ops3dxs.interpolate_correct_relax(ctx, v, f, n3, rg, c, 1), want), (on, zchunk)
+                assert ctx.last_corr_kernel().startswith(name), (on, ctx.last_corr_kernel())
+    finally:
+        ctx.set_param("relax3d.corr_v2", 1)
+        ctx.set_param("relax3d.zchunk", 0)
+
+
 @pytest.mark.parametrize("layout", ["natural", "xsplit"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n3", [(3, 3, 3), (9, 17, 9), (33, 17, 65), (129, 65, 17), (257, 129, 33), (513, 129, 17)])

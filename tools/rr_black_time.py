@@ -46,8 +46,10 @@ def run(reps):
     return ts
 
 
-cases = [("separate launches", {"rr3d.black": 0}), ("black pass inside, 16 waves", {"rr3d.black": 1, "rr3d.black_waves": 16}),
-         ("black pass inside, 12 waves", {"rr3d.black": 1, "rr3d.black_waves": 12}), ("separate launches", {"rr3d.black": 0})]
+ON = 2 if dtype == np.float32 else 1  # fp32 is not taken by default: force it
+cases = [("separate launches", {"rr3d.black": 0}), ("black pass inside, 16 waves", {"rr3d.black": ON, "rr3d.black_waves": 16}),
+         ("black pass inside, 12 waves", {"rr3d.black": ON, "rr3d.black_waves": 12}),
+         ("black pass inside, 8 waves x 2 per CU", {"rr3d.black": ON, "rr3d.black_waves": 8}), ("separate launches", {"rr3d.black": 0})]
 for name, params in cases:
     for k, val in params.items():
         ctx.set_param(k, val)
