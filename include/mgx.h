@@ -101,8 +101,9 @@ int mgx_ctx_device(const mgx_ctx* ctx, int* device);
  * power-of-two squared spacings the residual multiplies by the exact reciprocals instead of dividing (same bits);
  * "relax3d.corr_v2" 0/1: fp32 on wide levels, the correcting red pass with two pairs per lane like the plain passes;
  * "relax3d.zero_sweep" 0/1: relax_from_zero on the pipelined levels runs its first red and black pass as one launch;
- * "relax3d.resident" 0/1 and "relax3d.resident_min" (sweeps per call, default 3): all colour passes of a Relax call on a level
- * of 33 ... 129 points per row in one launch (single-rank contexts only);
+ * "relax3d.resident" 0 / 1 / 2 and "relax3d.resident_min" (sweeps per call, default 3): all colour passes of a Relax call on a level
+ * of 33 ... 129 points per row in one launch (single-rank contexts only) -- off / the tiles exchange once per sweep (default) / once
+ * per pass; "relax3d.resident_tile" 0 (by level) / 8: tiles of 8 x 8 lines always;
  * "rr3d.black" 0 / 1 / 2: the last black pass of the pre-smoothing inside the residual+restrict launch -- off / on the
  * HBM-bound levels / wherever the geometry allows (tests), "rr3d.black_waves" 0 (by precision), 8 (two workgroups per CU), 12, 16 waves per workgroup.
  * Unknown names and out-of-range values are rejected (MGX_ERR_INVALID). */

@@ -3351,8 +3351,11 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: relax3d.zero_sweep = %d not in {0, 1}", value);
         ctx->relax_zero_sweep = value;
     } else if (!strcmp(name, "relax3d.resident")) {
-        MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: relax3d.resident = %d not in {0, 1}", value);
+        MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "set_param: relax3d.resident = %d not in {0, 1, 2}", value);
         ctx->relax_resident = value;
+    } else if (!strcmp(name, "relax3d.resident_tile")) {
+        MGX_REQUIRE(value == 0 || value == 8, MGX_ERR_INVALID, "set_param: relax3d.resident_tile = %d not in {0, 8}", value);
+        ctx->resident_tile = value;
     } else if (!strcmp(name, "relax3d.resident_min")) {
         MGX_REQUIRE(value >= 1, MGX_ERR_INVALID, "set_param: relax3d.resident_min = %d < 1", value);
         ctx->relax_resident_min = value;

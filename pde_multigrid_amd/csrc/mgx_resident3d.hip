@@ -211,6 +211,228 @@ __global__ void __launch_bounds__(1024)
     }
 }
 
+// ------------------------------------------------------------------ the same with ONE exchange per sweep
+// The hand-off, not the arithmetic, is what a pass costs (~2-3 us against ~0.3 us).  Here the tiles exchange once per red+black
+// SWEEP instead of once per pass: after its black pass a tile publishes the black values of the lines within TWO of its faces;
+// before the next red pass it fetches, from its four face neighbours, their two outermost lines and, from its four diagonal
+// neighbours, the one corner line -- the black values around its first halo ring.  With those it relaxes the red points of the
+// first ring's face lines ITSELF (the same expression on the same inputs as the owner: the same bits), then the black points of
+// its own lines.  LDS holds the tile with a halo two lines deep.  Buffer: [sweep parity][tile][face][depth 2][RT lines][64]
+// elements; a neighbour can be one sweep ahead, never two, for the reason given above.
+template <class real, int RT>
+__global__ void __launch_bounds__(1024)
+    relax3d_xs_resident2_kernel(real* __restrict__ v, const real* __restrict__ f, int sx, int sy, int sz, real hx2, real hy2, real hz2,
+                                int nsweeps, int zero_start, int gy, int gz, void* __restrict__ xbuf, unsigned xbytes, SweepSync sync) {
+    constexpr int LS = RT + 4;                 // line slots per direction: own line r at slot r + 2
+    __shared__ real L[LS][LS][2][64];          // [row slot][plane slot][half][pair]
+    const Geo<XSplit, real> g(sx, sy);
+    const int lane = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int M = (sx + 1) >> 1;
+    const int ty = blockIdx.x % gy, tz = blockIdx.x / gy;
+    const int y0 = 1 + ty * RT, z0 = 1 + tz * RT;
+    const bool has_ym = ty > 0, has_yp = ty < gy - 1, has_zm = tz > 0, has_zp = tz < gz - 1;
+    const u64 ep = *sync.epoch;
+    const double rd = relax3d_rd<real>(hx2, hy2, hz2);
+    const unsigned depthsz = RT * 64, facesz = 2 * depthsz, tilesz = 4 * facesz, bufsz = gridDim.x * tilesz;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, (int)xbytes, 0x00020000);
+    auto interior = [&](int y, int z) { return y >= 1 && y <= sy - 2 && z >= 1 && z <= sz - 2; };
+
+    // ---- the tile and two lines around it from memory (all loads of a wave first, then LDS)
+    {
+        constexpr int NL = (LS * LS + 15) / 16;
+        real ta[NL], tb[NL];
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int idx = w + 16 * j;
+            const int y = y0 - 2 + idx / LS, z = z0 - 2 + idx % LS;
+            ta[j] = tb[j] = 0;
+            if (idx < LS * LS && y >= 0 && z >= 0 && y <= sy - 1 && z <= sz - 1) {
+                if (!(zero_start && interior(y, z))) {
+                    const real* row = v + g.row(y, z);
+                    if (lane < M) ta[j] = row[lane];
+                    if (lane < M - 1) tb[j] = row[g.H + lane];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int idx = w + 16 * j;
+            if (idx < LS * LS) {
+                L[idx / LS][idx % LS][0][lane] = ta[j];
+                L[idx / LS][idx % LS][1][lane] = tb[j];
+            }
+        }
+    }
+    // ---- the wave's lines: four of its own (both colours), two of the first halo ring (red only)
+    constexpr int BE = RT / 4;            // a wave owns BE x BE lines of the tile ...
+    constexpr int NO = BE * BE, NR = BE;  // ... and relaxes the red points of BE lines of the first halo ring
+    int la[NO + NR], lb[NO + NR], par[NO + NR];  // row slot, plane slot, parity (y + z) & 1
+    bool valid[NO + NR];
+    real fA[NO], fB[NO], fR[NR], xR[NO + NR];
+    const int face = w >> 2;  // the face whose halo lines this wave fetches and relaxes: 0 = y-, 1 = y+, 2 = z-, 3 = z+
+    const bool have = face == 0 ? has_ym : (face == 1 ? has_yp : (face == 2 ? has_zm : has_zp));
+#pragma unroll
+    for (int l = 0; l < NO + NR; l++) {
+        int ry, rz;  // line coordinates relative to the tile
+        if (l < NO) {
+            ry = BE * (w & 3) + (l % BE);
+            rz = BE * (w >> 2) + (l / BE);
+        } else {
+            const int k = BE * (w & 3) + (l - NO);
+            ry = face == 0 ? -1 : (face == 1 ? RT : k);
+            rz = face == 2 ? -1 : (face == 3 ? RT : k);
+        }
+        const int y = y0 + ry, z = z0 + rz;
+        la[l] = ry + 2;
+        lb[l] = rz + 2;
+        par[l] = (y + z) & 1;
+        valid[l] = interior(y, z) && (l < NO || have);
+        xR[l] = 0;
+        if (l < NO) fA[l] = fB[l] = 0;
+        else fR[l - NO] = 0;
+        if (valid[l]) {
+            const size_t row = g.row(y, z);
+            if (l < NO) {
+                if (lane < M) fA[l] = f[row + lane];
+                if (lane < M - 1) fB[l] = f[row + g.H + lane];
+            } else {
+                const int q = par[l];  // red (colour 0) sits in half par
+                if (q == 0 ? lane < M : lane < M - 1) fR[l - NO] = f[row + q * g.H + lane];
+            }
+            if (M - 1 == 64 && !zero_start) xR[l] = v[row + 64];
+        }
+    }
+    // ---- what the wave fetches before a sweep: depth 0 and 1 of BE lines of its face, and (waves 1, 5, 9, 13) one corner line
+    constexpr int NF = 2 * BE + 1;
+    unsigned fsrc[NF];  // element offset inside one parity's buffer
+    int fa[NF], fb[NF], fh[NF];
+    unsigned fneed = 0;
+#pragma unroll
+    for (int i = 0; i < NF; i++) {
+        int ry, rz, nb;
+        unsigned off;
+        if (i < 2 * BE) {
+            const int k = BE * (w & 3) + (i % BE), d = i / BE;
+            ry = face == 0 ? -1 - d : (face == 1 ? RT + d : k);
+            rz = face == 2 ? -1 - d : (face == 3 ? RT + d : k);
+            nb = face == 0 ? (int)blockIdx.x - 1 : (face == 1 ? (int)blockIdx.x + 1 : (face == 2 ? (int)blockIdx.x - gy : (int)blockIdx.x + gy));
+            off = (unsigned)(face ^ 1) * facesz + (unsigned)d * depthsz + (unsigned)k * 64u;
+            if (!have) nb = -1;
+        } else {
+            // corner c = face: 0 = (-1, -1), 1 = (-1, RT), 2 = (RT, -1), 3 = (RT, RT); the owner holds it in a y-face buffer, depth 0
+            const int c = face;
+            ry = c < 2 ? -1 : RT;
+            rz = (c & 1) ? RT : -1;
+            const bool ex = (c < 2 ? has_ym : has_yp) && ((c & 1) ? has_zp : has_zm) && (w & 3) == 1;
+            nb = ex ? (int)blockIdx.x + (c < 2 ? -1 : 1) + ((c & 1) ? gy : -gy) : -1;
+            off = (unsigned)(c < 2 ? 1 : 0) * facesz + (unsigned)((c & 1) ? 0 : RT - 1) * 64u;
+        }
+        const int y = y0 + ry, z = z0 + rz;
+        fa[i] = ry + 2;
+        fb[i] = rz + 2;
+        fh[i] = 1 ^ ((y + z) & 1);  // black (colour 1) sits in half 1 ^ parity
+        fsrc[i] = nb >= 0 ? (unsigned)nb * tilesz + off : 0u;
+        if (nb >= 0 && interior(y, z)) fneed |= 1u << i;
+    }
+    fneed = (unsigned)__builtin_amdgcn_readfirstlane((int)fneed);
+    __syncthreads();
+
+    auto relax_line = [&](int l, int q, real ff) -> real {  // the new value of lane's entry in half q of line l (any lane: callers mask)
+        const int a = la[l], b = lb[l];
+        const real oth = L[a][b][1 - q][lane];
+        real O, E;
+        if (q == 0) {
+            O = L[a][b][1][lane > 0 ? lane - 1 : 0];
+            E = oth;
+        } else {
+            O = oth;
+            const real t = L[a][b][0][lane < 63 ? lane + 1 : 63];
+            E = lane < 63 ? t : xR[l];
+        }
+        const real N = L[a - 1][b][q][lane], S = L[a + 1][b][q][lane], D = L[a][b - 1][q][lane], U = L[a][b + 1][q][lane];
+        return relax3d_point_rd<real>(O, E, N, S, D, U, ff, hx2, hy2, hz2, rd);
+    };
+    auto updated = [&](int q) { return q == 0 ? (lane >= 1 && lane <= M - 2) : lane <= M - 2; };
+
+    bool gave_up = false;
+    for (int s = 0; s < nsweeps; s++) {
+        if (s > 0) {
+            // ---- the neighbours' black values of sweep s - 1: all loads of a round first, then the tags
+            const unsigned base = (unsigned)((s - 1) & 1) * bufsz;
+            const u64 tag = pass_tag<real>(ep, s - 1);
+            real x[NF];
+            unsigned pending = fneed, spins = 0;
+            while (pending && !gave_up) {
+                asm volatile("" ::: "memory");  // fresh loads every time round
+                bool ok[NF];
+#pragma unroll
+                for (int i = 0; i < NF; i++) {
+                    ok[i] = true;
+                    if (pending & (1u << i)) ok[i] = get_tagged<real>(xr, base + fsrc[i] + (unsigned)lane, tag, &x[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < NF; i++)
+                    if ((pending & (1u << i)) && __builtin_amdgcn_readfirstlane((int)__all(ok[i]))) pending &= ~(1u << i);
+                if (pending && (++spins > SWEEP_SPIN_LIMIT ||
+                                ((spins & 1023u) == 0 && __hip_atomic_load(sync.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0))) {
+                    if (lane == 0) __hip_atomic_store(sync.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    gave_up = true;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NF; i++)
+                if ((fneed & (1u << i)) && updated(fh[i])) L[fa[i]][fb[i]][fh[i]][lane] = x[i];  // boundary entries keep their value
+            __syncthreads();
+        }
+        // ---- red (colour 0, N3/MultiGrid3D.cpp:515) on the wave's own lines and its lines of the first halo ring
+#pragma unroll
+        for (int l = 0; l < NO + NR; l++) {
+            if (!valid[l]) continue;
+            const int q = par[l];
+            const real nv = relax_line(l, q, l < NO ? (q ? fB[l < NO ? l : 0] : fA[l < NO ? l : 0]) : fR[l < NO ? 0 : l - NO]);
+            if (updated(q)) L[la[l]][lb[l]][q][lane] = nv;
+        }
+        __syncthreads();
+        // ---- black (:544) on the own lines; their values to the neighbours
+        const unsigned dst = (unsigned)(s & 1) * bufsz + blockIdx.x * tilesz;
+        const u64 mytag = pass_tag<real>(ep, s);
+#pragma unroll
+        for (int l = 0; l < NO; l++) {
+            if (!valid[l]) continue;
+            const int q = 1 ^ par[l];
+            const real nv = relax_line(l, q, q ? fB[l] : fA[l]);
+            if (updated(q)) L[la[l]][lb[l]][q][lane] = nv;
+            if (s + 1 < nsweeps) {
+                const int ry = la[l] - 2, rz = lb[l] - 2;
+                if (ry <= 1 && has_ym) put_tagged<real>(xr, dst + 0 * facesz + (unsigned)ry * depthsz + (unsigned)rz * 64u + (unsigned)lane, nv, mytag);
+                if (ry >= RT - 2 && has_yp) put_tagged<real>(xr, dst + 1 * facesz + (unsigned)(RT - 1 - ry) * depthsz + (unsigned)rz * 64u + (unsigned)lane, nv, mytag);
+                if (rz <= 1 && has_zm) put_tagged<real>(xr, dst + 2 * facesz + (unsigned)rz * depthsz + (unsigned)ry * 64u + (unsigned)lane, nv, mytag);
+                if (rz >= RT - 2 && has_zp) put_tagged<real>(xr, dst + 3 * facesz + (unsigned)(RT - 1 - rz) * depthsz + (unsigned)ry * 64u + (unsigned)lane, nv, mytag);
+            }
+        }
+        // (the barrier behind the next sweep's fetch orders these LDS writes before their readers; the fetch itself writes only
+        // black entries of halo lines, which nobody reads during a black pass)
+    }
+    __syncthreads();
+    // ---- the tile back to memory (interior entries)
+#pragma unroll
+    for (int l = 0; l < NO; l++) {
+        if (!valid[l]) continue;
+        real* row = v + g.row(y0 + la[l] - 2, z0 + lb[l] - 2);
+        if (lane >= 1 && lane <= M - 2) row[lane] = L[la[l]][lb[l]][0][lane];
+        if (lane <= M - 2) row[g.H + lane] = L[la[l]][lb[l]][1][lane];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const unsigned old = __hip_atomic_fetch_add(sync.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            __hip_atomic_store(sync.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync.epoch, ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // Does a Relax call of `ncycles` sweeps on this level run in the resident kernel?  Rows of 33 ... 129 points (below: the
 // one-workgroup kernels; above: the level does not fit), all tiles resident at once, a context that has the GPU to itself
 // (thread-ranks and ranks of a communicator launch side by side: co-residency is not given), enough passes to pay for the load
@@ -241,21 +463,40 @@ int prepare_handoffs(mgx_ctx* ctx) {
     SweepSync sync;
     MGX_TRY_RET(sweep_state(ctx, &sync));
     const int tiles = ctx->num_cus < SWEEP_MAX_WG ? ctx->num_cus : SWEEP_MAX_WG;
-    return resident_buffer(ctx, (size_t)2 * tiles * 4 * RT * 64 * 16);
+    return resident_buffer(ctx, (size_t)2 * tiles * 4 * 2 * RT * 64 * 16);
 }
 
 template <class real>
 int relax3d_resident(mgx_ctx* ctx, real* v, const real* f, const int n[3], real hx2, real hy2, real hz2, int ncycles, int zero_start) {
-    const int gy = ceil_div(n[1] - 2, RT), gz = ceil_div(n[2] - 2, RT);
+    // "relax3d.resident": 1 = one exchange per sweep, 2 = one per pass.  A call of ONE sweep always takes the per-pass form: its
+    // single exchange is also what keeps a tile from writing its lines back before the neighbours have loaded them as their halo
+    // (with an exchange per sweep a one-sweep launch has none)
+    const bool per_sweep = ctx->relax_resident == 1 && ncycles >= 2;
+    // tiles of 4 x 4 lines where the level then still has at most one workgroup per CU (33^3: 64, 65^3: 256 workgroups): the passes
+    // are bound by instruction issue, a quarter of the lines per workgroup is worth more than the larger share of halo lines
+    int rt = RT;
+    if (per_sweep && ctx->resident_tile != 8 && ceil_div(n[1] - 2, 4) * ceil_div(n[2] - 2, 4) <= (ctx->num_cus < SWEEP_MAX_WG ? ctx->num_cus : SWEEP_MAX_WG)) rt = 4;
+    const int gy = ceil_div(n[1] - 2, rt), gz = ceil_div(n[2] - 2, rt);
     SweepSync sync;
     MGX_TRY_RET(sweep_state(ctx, &sync));
-    const size_t bytes = (size_t)2 * gy * gz * 4 * RT * 64 * 16;
+    const size_t bytes = (size_t)2 * gy * gz * 4 * 2 * rt * 64 * 16;  // the per-sweep form's lay-out; the per-pass form uses half of it
     MGX_TRY_RET(resident_buffer(ctx, bytes));
-    snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_resident_kernel<%s>", sizeof(real) == 8 ? "double" : "float");
-    for (int left = ncycles, first = 1; left > 0; first = 0) {  // a tag has 20 bits for the pass
-        const int k = left < (1 << 18) ? left : (1 << 18);
-        hipLaunchKernelGGL((relax3d_xs_resident_kernel<real>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2,
-                           hz2, 2 * k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)ctx->resident_bytes, sync);
+    if (per_sweep)
+        snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_resident2_kernel<%s,%d>", sizeof(real) == 8 ? "double" : "float", rt);
+    else
+        snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_resident_kernel<%s>", sizeof(real) == 8 ? "double" : "float");
+    for (int left = ncycles, first = 1; left > 0; first = 0) {  // a tag has 20 bits for the pass / sweep
+        int k = left < (1 << 18) ? left : (1 << 18);
+        if (per_sweep && left - k == 1) k--;  // never leave a launch of one sweep behind
+        if (per_sweep && rt == 4)
+            hipLaunchKernelGGL((relax3d_xs_resident2_kernel<real, 4>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2,
+                               hy2, hz2, k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)ctx->resident_bytes, sync);
+        else if (per_sweep)
+            hipLaunchKernelGGL((relax3d_xs_resident2_kernel<real, 8>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2,
+                               hy2, hz2, k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)ctx->resident_bytes, sync);
+        else
+            hipLaunchKernelGGL((relax3d_xs_resident_kernel<real>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2,
+                               hy2, hz2, 2 * k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)ctx->resident_bytes, sync);
         left -= k;
     }
     return MGX_OK;

@@ -481,13 +481,67 @@ __global__ void __launch_bounds__(1024) sweep3d_xs_mid_kernel(const real* __rest
     real* Rd = B + (size_t)BP * (TZ + 4);
     const int nt = blockDim.x, tid = threadIdx.x;
     const SmallDiv dM(M);
-    // Every phase works through its items in chunks of U per thread: first ALL global loads of a chunk are issued (old values,
-    // f), then the chunk is computed -- one memory round trip per chunk instead of one per item (items are independent).
+    // The red and the black phase each have at most UC items per thread (the host checks it).  Their global loads (f at the
+    // points they relax, the boundary values the red phase passes on) do not depend on anything computed here, so ALL of them
+    // are requested before the old black values are staged: one memory round trip for the whole launch instead of three in a
+    // row (measured: 65^3 8.4 -> see DESIGN section 5, 33^3 likewise; the launch is latency, not bytes).
+    constexpr int UC = 4;
+    real fr[UC], fb[UC];
+    int rli[UC], rbi[UC], rkind[UC], rg[UC];  // red items; rkind: -1 none, 0 no point (x = sx), 1 boundary (fr = its value), 2 interior halo, 3 interior own
+    int bpi[UC], bg[UC];                      // black items; bpi < 0: none
+    {
+        const int NY = rb - ra, n = (sb - sa) * NY * M;
+        const SmallDiv dNY(NY);
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const int t = tid + u * nt;
+            rkind[u] = -1;
+            fr[u] = 0;
+            rli[u] = rbi[u] = rg[u] = 0;
+            if (t < n) {
+                const int r = dM(t), i = t - r * M, zz = dNY(r), yy = r - zz * NY, y = ra + yy, z = sa + zz;
+                const int q = (c0 + y + z) & 1, x = 2 * i + q;
+                rli[u] = i + yy * RW + zz * RP;
+                rbi[u] = (i + (y - ya) * BW + (z - za) * BP) * 2 + q;
+                rkind[u] = 0;
+                if (x < sx) {
+                    rg[u] = (int)(g.row(y, z) + q * H + i);
+                    if (x == 0 || x == sx - 1 || y == 0 || y == sy - 1 || z == 0 || z == sz - 1) {
+                        rkind[u] = 1;
+                        if (!ZERO) fr[u] = vin[rg[u]];
+                    } else {
+                        rkind[u] = (y >= y0 && y < y1 && z >= z0 && z < z1) ? 3 : 2;
+                        fr[u] = f[rg[u]];
+                    }
+                }
+            }
+        }
+    }
+    {
+        const int NY = y1 - y0, n = (z1 - z0) * NY * M;
+        const SmallDiv dNY(NY);
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const int t = tid + u * nt;
+            bpi[u] = -1;
+            fb[u] = 0;
+            bg[u] = 0;
+            if (t < n) {
+                const int r = dM(t), i = t - r * M, zz = dNY(r), y = y0 + r - zz * NY, z = z0 + zz;
+                const int q = (c0 + 1 + y + z) & 1, x = 2 * i + q;
+                if (x >= 1 && x < sx - 1) {
+                    bg[u] = (int)(g.row(y, z) + q * H + i);
+                    bpi[u] = (i + (y - ra) * RW + (z - sa) * RP) * 2 + q;
+                    fb[u] = f[bg[u]];
+                }
+            }
+        }
+    }
+    // 1. the old black values of the rows [ya, yb) x [za, zb) (ZERO: zeros, nothing is read), in chunks of U per thread: first all
+    // loads of a chunk, then its LDS stores.  ZERO is a run-time flag: as a template parameter the specialised kernel gave wrong
+    // values next to boundary faces whenever the previous launch had left non-zero data in LDS (hipcc 7.2; found by sweep_once
+    // against the oracle, not understood) -- the generic code path with two selects is bit-exact.
     constexpr int U = 6;
-    // 1. the old black values of the rows [ya, yb) x [za, zb) (ZERO: zeros, nothing is read).  ZERO is a run-time flag: as a
-    // template parameter the specialised kernel gave wrong values next to boundary faces whenever the previous launch had left
-    // non-zero data in LDS (hipcc 7.2; found by sweep_once against the oracle, not understood) -- the generic code path with
-    // two selects is bit-exact.
     {
         const int NY = yb - ya, n = (zb - za) * NY * M;
         const SmallDiv dNY(NY);
@@ -513,90 +567,31 @@ __global__ void __launch_bounds__(1024) sweep3d_xs_mid_kernel(const real* __rest
     }
     __syncthreads();
     // 2. red on the tile and one row / plane around it (boundary points keep their value)
-    {
-        const int NY = rb - ra, n = (sb - sa) * NY * M;
-        const SmallDiv dNY(NY);
-        for (int base = tid; base < n; base += nt * U) {
-            real fv[U];
-            int li[U], bi[U], kind[U];  // kind: -1 none, 0 no point (x = sx), 1 boundary (fv = its value), 2 interior halo, 3 interior own
-            size_t gidx[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int t = base + u * nt;
-                kind[u] = -1;
-                fv[u] = 0;
-                li[u] = bi[u] = 0;
-                gidx[u] = 0;
-                if (t < n) {
-                    const int r = dM(t), i = t - r * M, zz = dNY(r), yy = r - zz * NY, y = ra + yy, z = sa + zz;
-                    const int q = (c0 + y + z) & 1, x = 2 * i + q;
-                    li[u] = i + yy * RW + zz * RP;
-                    bi[u] = (i + (y - ya) * BW + (z - za) * BP) * 2 + q;
-                    kind[u] = 0;
-                    if (x < sx) {
-                        gidx[u] = g.row(y, z) + q * H + i;
-                        if (x == 0 || x == sx - 1 || y == 0 || y == sy - 1 || z == 0 || z == sz - 1) {
-                            kind[u] = 1;
-                            if (!ZERO) fv[u] = vin[gidx[u]];
-                        } else {
-                            kind[u] = (y >= y0 && y < y1 && z >= z0 && z < z1) ? 3 : 2;
-                            fv[u] = f[gidx[u]];
-                        }
-                    }
-                }
+    for (int u = 0; u < UC; u++) {
+        if (rkind[u] < 0) continue;
+        real val = (real)0;
+        if (!ZERO && rkind[u] == 1) val = fr[u];
+        if (rkind[u] >= 2) {
+            {
+                const int q = rbi[u] & 1;
+                const real* b = B + (rbi[u] >> 1);  // the pair's own black value (x + 1 - 2 q)
+                const real side = q ? b[1] : b[-1];
+                val = relax3d_point_rd<real>(q ? b[0] : side, q ? side : b[0], b[-BW], b[BW], b[-BP], b[BP], fr[u], hx2, hy2, hz2, rd);
             }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (kind[u] < 0) continue;
-                real val = (real)0;
-                if (!ZERO && kind[u] == 1) val = fv[u];
-                if (kind[u] >= 2) {
-                    {
-                        const int q = bi[u] & 1;
-                        const real* b = B + (bi[u] >> 1);  // the pair's own black value (x + 1 - 2 q)
-                        const real side = q ? b[1] : b[-1];
-                        val = relax3d_point_rd<real>(q ? b[0] : side, q ? side : b[0], b[-BW], b[BW], b[-BP], b[BP], fv[u], hx2, hy2, hz2, rd);
-                    }
-                    if (kind[u] == 3) vout[gidx[u]] = val;
-                }
-                Rd[li[u]] = val;
-            }
+            if (rkind[u] == 3) vout[rg[u]] = val;
         }
+        Rd[rli[u]] = val;
     }
     __syncthreads();
     // 3. black on the tile
-    {
-        const int NY = y1 - y0, n = (z1 - z0) * NY * M;
-        const SmallDiv dNY(NY);
-        for (int base = tid; base < n; base += nt * U) {
-            real fv[U];
-            int pi[U];
-            size_t gidx[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int t = base + u * nt;
-                pi[u] = -1;
-                fv[u] = 0;
-                gidx[u] = 0;
-                if (t < n) {
-                    const int r = dM(t), i = t - r * M, zz = dNY(r), y = y0 + r - zz * NY, z = z0 + zz;
-                    const int q = (c0 + 1 + y + z) & 1, x = 2 * i + q;
-                    if (x >= 1 && x < sx - 1) {
-                        gidx[u] = g.row(y, z) + q * H + i;
-                        pi[u] = (i + (y - ra) * RW + (z - sa) * RP) * 2 + q;
-                        fv[u] = f[gidx[u]];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (pi[u] < 0) continue;
-                const int q = pi[u] & 1;
-                const real* p = Rd + (pi[u] >> 1);  // the pair's own red value
-                const real side = q ? p[1] : p[-1];
-                vout[gidx[u]] = relax3d_point_rd<real>(q ? p[0] : side, q ? side : p[0], p[-RW], p[RW], p[-RP], p[RP], fv[u], hx2, hy2, hz2, rd);
-            }
-        }
+    for (int u = 0; u < UC; u++) {
+        if (bpi[u] < 0) continue;
+        const int q = bpi[u] & 1;
+        const real* p = Rd + (bpi[u] >> 1);  // the pair's own red value
+        const real side = q ? p[1] : p[-1];
+        vout[bg[u]] = relax3d_point_rd<real>(q ? p[0] : side, q ? side : p[0], p[-RW], p[RW], p[-RP], p[RP], fb[u], hx2, hy2, hz2, rd);
     }
 }
 
@@ -747,6 +742,8 @@ static int sweep3d_mid_launch(mgx_ctx* ctx, const real* vin, real* vout, const r
     const size_t lds = (size_t)((sx + 1) / 2) * ((TY + 4) * (TZ + 4) + (TY + 2) * (TZ + 2)) * sizeof(real);
     const int gy = ceil_div(sy - 2, TY), gz = ceil_div(sz - 2, TZ);
     const int threads = (size_t)TY * TZ * ((sx + 1) / 2) >= 2048 ? 1024 : 512;
+    MGX_REQUIRE((TY + 2) * (TZ + 2) * ((sx + 1) / 2) <= 4 * threads, MGX_ERR_SIZE, "sweep3d_mid: tile %d x %d of %d-point rows has more than 4 items per thread",
+                TY, TZ, sx);
     if (lds > 64 * 1024) {
         MGX_HIP(hipFuncSetAttribute((const void*)sweep3d_xs_mid_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }

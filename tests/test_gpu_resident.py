@@ -1,5 +1,6 @@
-"""GPU suite: all colour passes of a Relax call in ONE launch on the cache-resident levels (relax3d_xs_resident_kernel,
-csrc/mgx_resident3d.hip) against the oracle's MultiGrid3D::Relax restatement (N3/MultiGrid3D.cpp:489-567), bit for bit.
+"""GPU suite: all colour passes of a Relax call in ONE launch on the cache-resident levels (relax3d_xs_resident2_kernel: the
+tiles exchange once per sweep and relax the red points of their first halo ring themselves; relax3d_xs_resident_kernel: once per
+pass; csrc/mgx_resident3d.hip) against the oracle's MultiGrid3D::Relax restatement (N3/MultiGrid3D.cpp:489-567), bit for bit.
 The workgroups hand their face lines to each other through memory, ordered by progress words: every case checks every
 word of the result; sweep counts from 1 to a few hundred move the hand-offs and the double-buffered exchange around, tile
 counts from 1 x 1 to 16 x 16 put faces, partial tiles and the extra boundary entry of 129-point rows everywhere."""
@@ -14,12 +15,24 @@ pytestmark = pytest.mark.gpu
 RG = [-1, 1, 0, 2, 0.5, 3]
 
 
-@pytest.fixture(scope="module")
-def ctx():
+FORMS = {1: "relax3d_xs_resident2_kernel", 2: "relax3d_xs_resident_kernel"}  # "relax3d.resident": one exchange per sweep (default) / per pass
+
+
+@pytest.fixture(scope="module", params=[(1, 0), (1, 8), (2, 0)], ids=["per_sweep", "per_sweep_tiles8", "per_pass"])
+def ctx(request):
     c = P.Context(0)
+    c.form, tile = request.param
+    c.kernel = FORMS[c.form]
+    c.set_param("relax3d.resident", c.form)
+    c.set_param("relax3d.resident_tile", tile)  # 0: tiles of 4 x 4 lines where the level has at most one per CU then, else 8 x 8
     c.set_param("relax3d.resident_min", 1)
     yield c
     c.close()
+
+
+def _kernel(ctx, ncycles):
+    """a call of one sweep always runs the per-pass form (its one exchange orders the neighbours' halo loads before the write-back)"""
+    return ctx.kernel if ncycles >= 2 else FORMS[2]
 
 
 def _data(n3, dtype, seed=0):
@@ -34,7 +47,7 @@ def _data(n3, dtype, seed=0):
 def test_resident_relax_matches_oracle(ctx, n3, ncycles, dtype):
     v, f = _data(n3, dtype, seed=n3[0] + ncycles)  # random boundary values too
     got = P.ops3dxs.relax(ctx, v, f, n3, RG, ncycles)
-    assert ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel"), ctx.last_relax_kernel()
+    assert ctx.last_relax_kernel().startswith(_kernel(ctx, ncycles)), ctx.last_relax_kernel()
     ctx.sync()  # raises if a wait gave up
     assert bits_equal(got, O.relax3d(n3, RG, v, f, ncycles, dtype=dtype))
 
@@ -44,7 +57,7 @@ def test_resident_long_relax_calls(ctx, n3, ncycles):
     """the reference's own workloads call Relax with thousands of sweeps: hundreds of hand-offs per workgroup in one launch"""
     v, f = _data(n3, np.float32, seed=ncycles)
     got = P.ops3dxs.relax(ctx, v, f, n3, [0, 1, 0, 1, 0, 1], ncycles)
-    assert ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+    assert ctx.last_relax_kernel().startswith(ctx.kernel)
     ctx.sync()
     assert bits_equal(got, O.relax3d(n3, [0, 1, 0, 1, 0, 1], v, f, ncycles, dtype=np.float32))
 
@@ -58,7 +71,7 @@ def test_resident_from_zero(ctx, ncycles, dtype):
     v[:, 0] = v[:, -1] = 0
     v[:, :, 0] = v[:, :, -1] = 0
     got = P.ops3dxs.relax_from_zero(ctx, v, f, n3, RG, ncycles, True)
-    assert ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+    assert ctx.last_relax_kernel().startswith(_kernel(ctx, ncycles))
     ctx.sync()
     assert bits_equal(got, O.relax3d(n3, RG, np.zeros_like(v), f, ncycles, dtype=dtype))
 
@@ -76,21 +89,21 @@ def test_resident_many_launches_on_one_context_and_switches(ctx):
     ctx.set_param("relax3d.resident", 0)
     try:
         got = P.ops3dxs.relax(ctx, v, f, n3, RG, 2)
-        assert not ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+        assert not ctx.last_relax_kernel().startswith("relax3d_xs_resident")
         assert bits_equal(got, O.relax3d(n3, RG, v, f, 2, dtype=np.float64))
     finally:
-        ctx.set_param("relax3d.resident", 1)
+        ctx.set_param("relax3d.resident", ctx.form)
     ctx.set_param("relax3d.resident_min", 3)
     try:
         P.ops3dxs.relax(ctx, v, f, n3, RG, 2)
-        assert not ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+        assert not ctx.last_relax_kernel().startswith("relax3d_xs_resident")
         P.ops3dxs.relax(ctx, v, f, n3, RG, 3)
-        assert ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+        assert ctx.last_relax_kernel().startswith(ctx.kernel)
     finally:
         ctx.set_param("relax3d.resident_min", 1)
     big, fb = _data((257, 33, 33), np.float64)
     P.ops3dxs.relax(ctx, big, fb, (257, 33, 33), RG, 4)  # rows too long for one wave: the colour-pass kernels
-    assert not ctx.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+    assert not ctx.last_relax_kernel().startswith("relax3d_xs_resident")
 
 
 @pytest.mark.parametrize("dtype,mode", [(np.float32, 0), (np.float64, 0), (np.float32, 1)])
@@ -112,7 +125,7 @@ def test_resident_inside_the_hierarchy(dtype, mode):
         else:
             mg.VCycle(0, 3, 3)
             mg.VCycle(0, 3, 3)
-        assert c.last_relax_kernel().startswith("relax3d_xs_resident_kernel"), c.last_relax_kernel()
+        assert c.last_relax_kernel().startswith("relax3d_xs_resident2_kernel"), c.last_relax_kernel()
         got = mg.download_v(0)
         mg.close()
         c.sync()
@@ -133,7 +146,7 @@ def test_resident_inside_a_captured_cycle_on_a_fresh_context():
         mg.use_graph = True
         for _ in range(4):
             mg.VCycle(0, 3, 3)
-        assert c.last_relax_kernel().startswith("relax3d_xs_resident_kernel")
+        assert c.last_relax_kernel().startswith("relax3d_xs_resident2_kernel")
         got = mg.download_v(0)
         mg.close()
         c.sync()

@@ -28,8 +28,9 @@ for n in (33, 65, 129):
     h = _rp(grid_spacing(n3, [0, 1, 0, 1, 0, 1], dtype), ct)
     for ncycles in (2, 3, 10, 100, 3000):
         res = {}
-        for resident in (0, 1):
-            ctx.set_param("relax3d.resident", resident)
+        for resident in (0, 2, 8, 1):
+            ctx.set_param("relax3d.resident", 1 if resident == 8 else resident)
+            ctx.set_param("relax3d.resident_tile", 8 if resident == 8 else 0)
             ctx.set_param("relax3d.resident_min", 1)
             ts = []
             for i in range(7 if ncycles < 1000 else 3):
@@ -39,9 +40,11 @@ for n in (33, 65, 129):
                 ctx.sync()
                 ts.append(ctx.elapsed_ms(e0, e1))
             res[resident] = (sorted(ts)[len(ts) // 2], ctx.last_relax_kernel())
-        print("%3d^3 %s Relax(%4d): per-pass launches %9.4f ms (%.2f us per pass) [%s]   one launch %9.4f ms (%.2f us per pass)" % (
-            n, np.dtype(dtype).name, ncycles, res[0][0], res[0][0] * 1e3 / (2 * ncycles), res[0][1].split("<")[0], res[1][0],
-            res[1][0] * 1e3 / (2 * ncycles)), flush=True)
+        print("%3d^3 %s Relax(%4d): per-pass launches %9.4f ms (%.2f us per pass) [%s]   one launch, exchange per pass %9.4f ms (%.2f us per pass)"
+              "   exchange per sweep, tiles of 8: %9.4f ms (%.2f us per pass)   exchange per sweep %9.4f ms (%.2f us per pass) [%s]" % (
+                  n, np.dtype(dtype).name, ncycles, res[0][0], res[0][0] * 1e3 / (2 * ncycles), res[0][1].split("<")[0], res[2][0],
+                  res[2][0] * 1e3 / (2 * ncycles), res[8][0], res[8][0] * 1e3 / (2 * ncycles), res[1][0], res[1][0] * 1e3 / (2 * ncycles),
+                  res[1][1]), flush=True)
     ctx.free(pv)
     ctx.free(pf)
 ctx.close()
