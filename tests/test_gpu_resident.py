@@ -153,3 +153,23 @@ def test_resident_inside_a_captured_cycle_on_a_fresh_context():
         assert bits_equal(got, O.cycle3d(n3, RG, mode=0, v1=3, v2=3, reps=4, dtype=np.float32))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("n,sweeps", [(33, 300), (65, 120)])
+def test_thesis_shaped_fmg_with_long_relax_calls(n, sweeps):
+    """the shape of the reference's own workload (N3/Poisson3DSolver.cpp:18-20: FMG(2, 3000, 3000) on the unit cube, fp32, analytic
+    right-hand side) with fewer sweeps per call so that the oracle finishes in seconds: every level of 33 ... 65 points runs its
+    Relax calls in the resident kernel (one exchange per sweep, from zero on the way down), the levels below in the one-workgroup
+    kernel; the solution against the oracle's, bit for bit"""
+    n3 = [n] * 3
+    c = P.Context(0)
+    try:
+        mg = P.MultiGrid3D(c, n3, [0, 1, 0, 1, 0, 1], np.float32)
+        mg.FullMultiGridVCycle(0, 2, sweeps, sweeps)
+        got = mg.download_v(0)
+        mg.close()
+        c.sync()
+        want = O.cycle3d(n3, [0, 1, 0, 1, 0, 1], mode=1, v0=2, v1=sweeps, v2=sweeps, dtype=np.float32)
+        assert bits_equal(got, want)
+    finally:
+        c.close()
