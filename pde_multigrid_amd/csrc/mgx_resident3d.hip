@@ -56,6 +56,38 @@ __device__ __forceinline__ u64 pass_tag(u64 ep, int p) {
     return (ep << 20) | (u64)(p + 1);
 }
 
+// The per-sweep kernel's lines: only the lanes that hold entries (lane < M) take part, and fp32 packs the values of an even lane and
+// its odd neighbour into ONE element {v[2j], v[2j + 1], tag} -- at 65^3 and 129^3 the exchange is bound by the bytes it moves
+// (one line per relaxed line and sweep, 16 bytes per 4- or 8-byte value), not by its latency.  Element j of a line: fp64 lane j's
+// value, fp32 the values of lanes 2j and 2j + 1.  put_line is called by whole waves (it shuffles).
+template <class real>
+__device__ __forceinline__ void put_line(__amdgpu_buffer_rsrc_t r, unsigned line_elem, int lane, int M, real x, u64 tag) {
+    if constexpr (sizeof(real) == 4) {
+        const real x1 = __shfl_down(x, 1, 64);
+        if ((lane & 1) == 0 && lane < M) {
+            u32x4_t t;
+            t.x = __float_as_uint(x);
+            t.y = __float_as_uint(x1);
+            t.z = (unsigned)tag;
+            t.w = (unsigned)(tag >> 32);
+            __builtin_amdgcn_raw_buffer_store_b128(t, r, (line_elem + (unsigned)(lane >> 1)) * 16u, 0, 16);
+        }
+    } else {
+        if (lane < M) put_tagged<real>(r, line_elem + (unsigned)lane, x, tag);
+    }
+}
+template <class real>
+__device__ __forceinline__ bool get_line(__amdgpu_buffer_rsrc_t r, unsigned line_elem, int lane, int M, u64 tag, real* x) {
+    if (lane >= M) return true;
+    if constexpr (sizeof(real) == 4) {
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, (line_elem + (unsigned)(lane >> 1)) * 16u, 0, 16);
+        *x = __uint_as_float((lane & 1) ? t.y : t.x);
+        return (((u64)t.w << 32) | (u64)t.z) == tag;
+    } else {
+        return get_tagged<real>(r, line_elem + (unsigned)lane, tag, x);
+    }
+}
+
 template <class real>
 __global__ void __launch_bounds__(1024)
     relax3d_xs_resident_kernel(real* __restrict__ v, const real* __restrict__ f, int sx, int sy, int sz, real hx2, real hy2, real hz2,
@@ -338,19 +370,31 @@ __global__ void __launch_bounds__(1024)
     fneed = (unsigned)__builtin_amdgcn_readfirstlane((int)fneed);
     __syncthreads();
 
-    auto relax_line = [&](int l, int q, real ff) -> real {  // the new value of lane's entry in half q of line l (any lane: callers mask)
-        const int a = la[l], b = lb[l];
-        const real oth = L[a][b][1 - q][lane];
+    // LDS indices of the lane's entries of each line, formed ONCE and kept in vector registers (the empty asm makes them opaque:
+    // rebuilt from the wave-uniform slot numbers at every use they cost three scalar and one vector instruction per LDS access):
+    // ired = the entry in the half that holds the line's red point, iblk = the other half
+    real* const Lf = &L[0][0][0][0];
+    int ired[NO + NR], iblk[NO + NR];
+#pragma unroll
+    for (int l = 0; l < NO + NR; l++) {
+        const int i0 = (la[l] * LS + lb[l]) * 128 + lane;
+        ired[l] = i0 + par[l] * 64;
+        iblk[l] = i0 + (1 - par[l]) * 64;
+        asm volatile("" : "+v"(ired[l]), "+v"(iblk[l]));
+    }
+    // the new value of the entry at index iq (half q of its line; io = the same lane in the other half); any lane: callers mask
+    auto relax_at = [&](int iq, int io, int q, real ff, real xr_) -> real {
+        const real oth = Lf[io];
         real O, E;
         if (q == 0) {
-            O = L[a][b][1][lane > 0 ? lane - 1 : 0];
+            O = Lf[io - 1];  // lane 0: the entry in front of the half, in range, and x = 0 is never updated
             E = oth;
         } else {
             O = oth;
-            const real t = L[a][b][0][lane < 63 ? lane + 1 : 63];
-            E = lane < 63 ? t : xR[l];
+            const real t = Lf[io + 1];  // lane 63: the entry behind the half, in range, replaced by the line's boundary value
+            E = lane < 63 ? t : xr_;
         }
-        const real N = L[a - 1][b][q][lane], S = L[a + 1][b][q][lane], D = L[a][b - 1][q][lane], U = L[a][b + 1][q][lane];
+        const real N = Lf[iq - LS * 128], S = Lf[iq + LS * 128], D = Lf[iq - 128], U = Lf[iq + 128];
         return relax3d_point_rd<real>(O, E, N, S, D, U, ff, hx2, hy2, hz2, rd);
     };
     auto updated = [&](int q) { return q == 0 ? (lane >= 1 && lane <= M - 2) : lane <= M - 2; };
@@ -369,7 +413,7 @@ __global__ void __launch_bounds__(1024)
 #pragma unroll
                 for (int i = 0; i < NF; i++) {
                     ok[i] = true;
-                    if (pending & (1u << i)) ok[i] = get_tagged<real>(xr, base + fsrc[i] + (unsigned)lane, tag, &x[i]);
+                    if (pending & (1u << i)) ok[i] = get_line<real>(xr, base + fsrc[i], lane, M, tag, &x[i]);
                 }
 #pragma unroll
                 for (int i = 0; i < NF; i++)
@@ -390,8 +434,8 @@ __global__ void __launch_bounds__(1024)
         for (int l = 0; l < NO + NR; l++) {
             if (!valid[l]) continue;
             const int q = par[l];
-            const real nv = relax_line(l, q, l < NO ? (q ? fB[l < NO ? l : 0] : fA[l < NO ? l : 0]) : fR[l < NO ? 0 : l - NO]);
-            if (updated(q)) L[la[l]][lb[l]][q][lane] = nv;
+            const real nv = relax_at(ired[l], iblk[l], q, l < NO ? (q ? fB[l < NO ? l : 0] : fA[l < NO ? l : 0]) : fR[l < NO ? 0 : l - NO], xR[l]);
+            if (updated(q)) Lf[ired[l]] = nv;
         }
         __syncthreads();
         // ---- black (:544) on the own lines; their values to the neighbours
@@ -401,14 +445,14 @@ __global__ void __launch_bounds__(1024)
         for (int l = 0; l < NO; l++) {
             if (!valid[l]) continue;
             const int q = 1 ^ par[l];
-            const real nv = relax_line(l, q, q ? fB[l] : fA[l]);
-            if (updated(q)) L[la[l]][lb[l]][q][lane] = nv;
+            const real nv = relax_at(iblk[l], ired[l], q, q ? fB[l] : fA[l], xR[l]);
+            if (updated(q)) Lf[iblk[l]] = nv;
             if (s + 1 < nsweeps) {
                 const int ry = la[l] - 2, rz = lb[l] - 2;
-                if (ry <= 1 && has_ym) put_tagged<real>(xr, dst + 0 * facesz + (unsigned)ry * depthsz + (unsigned)rz * 64u + (unsigned)lane, nv, mytag);
-                if (ry >= RT - 2 && has_yp) put_tagged<real>(xr, dst + 1 * facesz + (unsigned)(RT - 1 - ry) * depthsz + (unsigned)rz * 64u + (unsigned)lane, nv, mytag);
-                if (rz <= 1 && has_zm) put_tagged<real>(xr, dst + 2 * facesz + (unsigned)rz * depthsz + (unsigned)ry * 64u + (unsigned)lane, nv, mytag);
-                if (rz >= RT - 2 && has_zp) put_tagged<real>(xr, dst + 3 * facesz + (unsigned)(RT - 1 - rz) * depthsz + (unsigned)ry * 64u + (unsigned)lane, nv, mytag);
+                if (ry <= 1 && has_ym) put_line<real>(xr, dst + 0 * facesz + (unsigned)ry * depthsz + (unsigned)rz * 64u, lane, M, nv, mytag);
+                if (ry >= RT - 2 && has_yp) put_line<real>(xr, dst + 1 * facesz + (unsigned)(RT - 1 - ry) * depthsz + (unsigned)rz * 64u, lane, M, nv, mytag);
+                if (rz <= 1 && has_zm) put_line<real>(xr, dst + 2 * facesz + (unsigned)rz * depthsz + (unsigned)ry * 64u, lane, M, nv, mytag);
+                if (rz >= RT - 2 && has_zp) put_line<real>(xr, dst + 3 * facesz + (unsigned)(RT - 1 - rz) * depthsz + (unsigned)ry * 64u, lane, M, nv, mytag);
             }
         }
         // (the barrier behind the next sweep's fetch orders these LDS writes before their readers; the fetch itself writes only
