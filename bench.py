@@ -184,6 +184,26 @@ def run_secondary(P, ctx, np):
         lambda: P.MultiGrid3D(ctx, [257] * 3, R3, np.float64, nlevels=6), 3, 257, 6, 50)
     run("3D Poisson 513^3, 9 levels, f32 (the reference's precision), V(2,2)", "3d_n513_vcycle22_9lev_f32",
         lambda: P.MultiGrid3D(ctx, [513] * 3, R3, np.float32), 3, 513, 9, 20)
+    # the reference's PUBLISHED workload (thesis Fig. 4.4 = BASELINE.md section 1: whole-program wall time, fp32): construction + RHS +
+    # FMG(2, 3000, 3000) + download, n = 129; the thesis' GPU (GeForce GTX 550 Ti) took 39.1 s, its CPU run stopped at n = 65 (213.4 s)
+    key = "3d_n129_fmg_2_3000_3000_f32"
+    ka = known.get(key)
+    ctx.sync()
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        mg = P.MultiGrid3D(ctx, [129] * 3, R3, np.float32)
+        mg.FullMultiGridVCycle(0, 2, 3000, 3000)
+        got = mg.download_v(0)
+        mg.close()
+        ctx.sync()
+        ts.append(time.perf_counter() - t0)
+    s1, s2 = checksum(got)
+    updates = 6000 * 2 * sum((j + 1) * (sz - 2) ** 3 for j, sz in enumerate(level_sizes(129, 7)))  # BASELINE.md section 1's count
+    status = "no known answer" if ka is None else ("ok" if ("%016x" % s1, "%016x" % s2) == (ka["sum64"], ka["wsum64"]) else "MISMATCH")
+    out["published workload: 3D Poisson FMG(2,3000,3000) 129^3, 7 levels, f32, whole program"] = {
+        "seconds": round(min(ts), 4), "runs_s": [round(t, 4) for t in ts], "published_seconds": {"GeForce GTX 550 Ti (thesis Fig. 4.4)": 39.1},
+        "mlups": round(updates / min(ts) / 1e6, 1), "result_check": status, "known_answer": key}
     return out
 
 

@@ -79,6 +79,19 @@ def secondary(data):
             print(k, data[k]["fnv"], data[k]["centre"], flush=True)
 
 
+def thesis(data, sizes):
+    """the reference's published 3D workload (thesis Fig. 4.4 = BASELINE.md section 1; N3/Poisson3DSolver.cpp:18-20): full multigrid
+    with 2 V-cycles per level and 3000 + 3000 sweeps per visit, fp32 = restatement<float> = the compiled reference's bits.
+    n = 129 takes about ten minutes on one core: `python oracle/gen_known_f64.py thesis [65] [129]`"""
+    for n in sizes:
+        v = O.cycle3d([n] * 3, R3, mode=1, v0=2, v1=3000, v2=3000, dtype=np.float32)
+        s1, s2 = checksum64(v)
+        key = "3d_n%d_fmg_2_3000_3000_f32" % n
+        data[key] = {"n": n, "nlevels": O.num_grids(n), "v0": 2, "v1": 3000, "v2": 3000, "dtype": "f32", "fnv": O.fnv(v), "sum64": s1,
+                     "wsum64": s2, "centre": float(v[n // 2, n // 2, n // 2])}
+        print(key, data[key]["fnv"], data[key]["centre"], flush=True)
+
+
 def main():
     """arguments: sizes, each optionally suffixed with the type, e.g. `513 1025 513:f32` (default f64).  fp32 cases are
     restatement<float>, which is bit-identical to the compiled reference (tests/test_oracle_vs_ref.py)"""
@@ -87,6 +100,11 @@ def main():
     if os.path.exists(OUT):
         with open(OUT) as fh:
             data = json.load(fh)
+    if todo and todo[0] == ["thesis"]:
+        thesis(data, [int(t[0]) for t in todo[1:]] or [65, 129])
+        with open(OUT, "w") as fh:
+            json.dump(data, fh, indent=1, sort_keys=True)
+        return
     if todo == [["secondary"]]:
         secondary(data)
         with open(OUT, "w") as fh:

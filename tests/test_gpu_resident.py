@@ -173,3 +173,25 @@ def test_thesis_shaped_fmg_with_long_relax_calls(n, sweeps):
         assert bits_equal(got, want)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("n", [65, 129])
+def test_published_workload_full_parameters_known_answer(n):
+    """the reference's published 3D workload with its own parameters (thesis Fig. 4.4 = BASELINE.md section 1; N3/Poisson3DSolver.cpp:18-20:
+    FMG with 2 V-cycles per level, 3000 + 3000 sweeps per visit, fp32, unit cube) against the hash of the oracle's result (generated once
+    by oracle/gen_known_f64.py thesis: ten CPU minutes at n = 129; restatement<float> = the compiled reference's bits)"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "known_answers_f64.json")) as fh:
+        ka = json.load(fh)["3d_n%d_fmg_2_3000_3000_f32" % n]
+    c = P.Context(0)
+    try:
+        mg = P.MultiGrid3D(c, [n] * 3, [0, 1, 0, 1, 0, 1], np.float32)
+        assert mg.numGrids == ka["nlevels"]
+        mg.FullMultiGridVCycle(0, 2, 3000, 3000)
+        got = mg.download_v(0)
+        mg.close()
+        c.sync()
+        assert O.fnv(got) == ka["fnv"] and float(got[n // 2, n // 2, n // 2]) == ka["centre"]
+    finally:
+        c.close()
