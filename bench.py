@@ -204,6 +204,24 @@ def run_secondary(P, ctx, np):
     out["published workload: 3D Poisson FMG(2,3000,3000) 129^3, 7 levels, f32, whole program"] = {
         "seconds": round(min(ts), 4), "runs_s": [round(t, 4) for t in ts], "published_seconds": {"GeForce GTX 550 Ti (thesis Fig. 4.4)": 39.1},
         "mlups": round(updates / min(ts) / 1e6, 1), "result_check": status, "known_answer": key}
+    # and the published 2D workload (thesis Fig. 4.2: Lyapunov FMG(2, 500, 500) on [0, 20]^2, n = 4097: 21.4 s on the thesis' GPU)
+    key = "2d_n4097_fmg_2_500_500_f32"
+    ka = known.get(key)
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        mg = P.MultiGrid2D(ctx, [4097] * 2, [0, 20, 0, 20], [-1, -2, 0, -3], 2, np.float32)
+        mg.FullMultiGridVCycle(0, 2, 500, 500)
+        got = mg.download_v(0)
+        mg.close()
+        ctx.sync()
+        ts.append(time.perf_counter() - t0)
+    s1, s2 = checksum(got)
+    updates = 1000 * 2 * sum((j + 1) * (sz - 2) ** 2 for j, sz in enumerate(level_sizes(4097, 12)))
+    status = "no known answer" if ka is None else ("ok" if ("%016x" % s1, "%016x" % s2) == (ka["sum64"], ka["wsum64"]) else "MISMATCH")
+    out["published workload: 2D Lyapunov FMG(2,500,500) 4097^2 on [0,20]^2, 12 levels, f32, whole program"] = {
+        "seconds": round(min(ts), 4), "runs_s": [round(t, 4) for t in ts], "published_seconds": {"GeForce GTX 550 Ti (thesis Fig. 4.2)": 21.4},
+        "mlups": round(updates / min(ts) / 1e6, 1), "result_check": status, "known_answer": key}
     return out
 
 

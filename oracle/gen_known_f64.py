@@ -92,6 +92,18 @@ def thesis(data, sizes):
         print(key, data[key]["fnv"], data[key]["centre"], flush=True)
 
 
+def thesis2d(data, sizes):
+    """the reference's published 2D workload (thesis Fig. 4.2 = BASELINE.md section 1; N2/LyapunovSolver.cpp:13-31 on [0, 20]^2): full
+    multigrid with 2 V-cycles per level and 500 + 500 sweeps per visit, fp32.  `python oracle/gen_known_f64.py thesis2d [1025] [4097]`"""
+    for n in sizes:
+        v = O.cycle2d([n] * 2, [0, 20, 0, 20], [-1.0, -2.0, 0.0, -3.0], 2, mode=1, v0=2, v1=500, v2=500, dtype=np.float32)
+        s1, s2 = checksum64(v)
+        key = "2d_n%d_fmg_2_500_500_f32" % n
+        data[key] = {"n": n, "nlevels": O.num_grids(n), "v0": 2, "v1": 500, "v2": 500, "dtype": "f32", "fnv": O.fnv(v), "sum64": s1,
+                     "wsum64": s2, "centre": float(v[n // 2, n // 2])}
+        print(key, data[key]["fnv"], data[key]["centre"], flush=True)
+
+
 def main():
     """arguments: sizes, each optionally suffixed with the type, e.g. `513 1025 513:f32` (default f64).  fp32 cases are
     restatement<float>, which is bit-identical to the compiled reference (tests/test_oracle_vs_ref.py)"""
@@ -102,6 +114,11 @@ def main():
             data = json.load(fh)
     if todo and todo[0] == ["thesis"]:
         thesis(data, [int(t[0]) for t in todo[1:]] or [65, 129])
+        with open(OUT, "w") as fh:
+            json.dump(data, fh, indent=1, sort_keys=True)
+        return
+    if todo and todo[0] == ["thesis2d"]:
+        thesis2d(data, [int(t[0]) for t in todo[1:]] or [1025, 4097])
         with open(OUT, "w") as fh:
             json.dump(data, fh, indent=1, sort_keys=True)
         return

@@ -45,6 +45,6 @@ def test_default_line_contract_and_secondary_configs():
     down = out["roofline_down"]  # the fused last black pass + residual + restrict launch of the finest level
     assert down["kernel"].startswith("relax_rr3d_xs_kernel<double") and 0.2 < down["frac"] < 1.0 and down["avg_launch_us"] > 100
     sec = out["secondary"]
-    assert len(sec) == 4 and all(c["result_check"] == "ok" for c in sec.values()), sec  # configs[1], [2], fp32, the published workload
+    assert len(sec) == 5 and all(c["result_check"] == "ok" for c in sec.values()), sec  # configs[1], [2], fp32, the two published workloads
     pub = [c for k, c in sec.items() if k.startswith("published workload")][0]
     assert 0.05 < pub["seconds"] < 5.0 and pub["known_answer"] == "3d_n129_fmg_2_3000_3000_f32"

@@ -708,6 +708,23 @@ def test_2d_baseline_config1_1025_f64(ctx):
     mg.close()
 
 
+@pytest.mark.parametrize("n", [1025, 4097])
+def test_2d_published_workload_full_parameters_known_answer(ctx, n):
+    """the reference's published 2D workload with its own parameters (thesis Fig. 4.2 = BASELINE.md section 1; N2/LyapunovSolver.cpp:13-31
+    on [0, 20]^2: FMG with 2 V-cycles per level, 500 + 500 sweeps per visit, fp32) against the hash of the oracle's result
+    (oracle/gen_known_f64.py thesis2d: minutes of CPU at 4097^2; restatement<float> = the compiled reference's bits)"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "known_answers_f64.json")) as fh:
+        ka = json.load(fh)["2d_n%d_fmg_2_500_500_f32" % n]
+    mg = P.MultiGrid2D(ctx, [n] * 2, [0, 20, 0, 20], A2, 2, np.float32)
+    assert mg.numGrids == ka["nlevels"]
+    mg.FullMultiGridVCycle(0, 2, 500, 500)
+    got = mg.download_v(0)
+    mg.close()
+    assert O.fnv(got) == ka["fnv"] and float(got[n // 2, n // 2]) == ka["centre"]
+
+
 @pytest.mark.parametrize("layout", ["xsplit", "natural"])
 def test_3d_coarse_rhs_rim_is_zero_after_every_cycle(ctx, layout):
     """the cycle re-zeroes the boundary entries of a coarse level's f only when something wrote there since the last
