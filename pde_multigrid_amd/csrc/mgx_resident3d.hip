@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(1024)
     constexpr int NO = BE * BE, NR = BE;  // ... and relaxes the red points of BE lines of the first halo ring
     int la[NO + NR], lb[NO + NR], par[NO + NR];  // row slot, plane slot, parity (y + z) & 1
     bool valid[NO + NR];
-    real fA[NO], fB[NO], fR[NR], xR[NO + NR];
+    real fred[NO + NR], fblk[NO], xR[NO + NR];  // f at the line's red / black points (halo lines: red only), the boundary entry past lane 63
     const int face = w >> 2;  // the face whose halo lines this wave fetches and relaxes: 0 = y-, 1 = y+, 2 = z-, 3 = z+
     const bool have = face == 0 ? has_ym : (face == 1 ? has_yp : (face == 2 ? has_zm : has_zp));
 #pragma unroll
@@ -321,16 +321,19 @@ __global__ void __launch_bounds__(1024)
         par[l] = (y + z) & 1;
         valid[l] = interior(y, z) && (l < NO || have);
         xR[l] = 0;
-        if (l < NO) fA[l] = fB[l] = 0;
-        else fR[l - NO] = 0;
+        fred[l] = 0;
+        if (l < NO) fblk[l] = 0;
         if (valid[l]) {
             const size_t row = g.row(y, z);
             if (l < NO) {
-                if (lane < M) fA[l] = f[row + lane];
-                if (lane < M - 1) fB[l] = f[row + g.H + lane];
+                real a = 0, b = 0;
+                if (lane < M) a = f[row + lane];
+                if (lane < M - 1) b = f[row + g.H + lane];
+                fred[l] = par[l] ? b : a;  // red (colour 0) sits in half par, black in the other
+                fblk[l] = par[l] ? a : b;
             } else {
-                const int q = par[l];  // red (colour 0) sits in half par
-                if (q == 0 ? lane < M : lane < M - 1) fR[l - NO] = f[row + q * g.H + lane];
+                const int q = par[l];
+                if (q == 0 ? lane < M : lane < M - 1) fred[l] = f[row + q * g.H + lane];
             }
             if (M - 1 == 64 && !zero_start) xR[l] = v[row + 64];
         }
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(1024)
         for (int l = 0; l < NO + NR; l++) {
             if (!valid[l]) continue;
             const int q = par[l];
-            const real nv = relax_at(ired[l], iblk[l], q, l < NO ? (q ? fB[l < NO ? l : 0] : fA[l < NO ? l : 0]) : fR[l < NO ? 0 : l - NO], xR[l]);
+            const real nv = relax_at(ired[l], iblk[l], q, fred[l], xR[l]);
             if (updated(q)) Lf[ired[l]] = nv;
         }
         __syncthreads();
@@ -445,7 +448,7 @@ __global__ void __launch_bounds__(1024)
         for (int l = 0; l < NO; l++) {
             if (!valid[l]) continue;
             const int q = 1 ^ par[l];
-            const real nv = relax_at(iblk[l], ired[l], q, q ? fB[l] : fA[l], xR[l]);
+            const real nv = relax_at(iblk[l], ired[l], q, fblk[l], xR[l]);
             if (updated(q)) Lf[iblk[l]] = nv;
             if (s + 1 < nsweeps) {
                 const int ry = la[l] - 2, rz = lb[l] - 2;
