@@ -289,6 +289,11 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     /* interpolate_correct writes the fine planes 2pz and 2pz+1 of every listed pz (z = 0 skipped).   */ \
     int mgx3dxs_relax_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy,           \
                                         const real h[3], int colour, int zbeg, int zend, int zoff);     \
+    /* relax_colour_slab2: the same pass over TWO runs of local planes [zb1, ze1) and [zb2, ze2), ze1   */ \
+    /* <= zb2, in one launch where both are short (the bottom and the top edge of a slab)               */ \
+    int mgx3dxs_relax_colour_slab2_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy,          \
+                                         const real h[3], int colour, int zb1, int ze1, int zb2,        \
+                                         int ze2, int zoff);                                             \
     /* relax_zero_colour_slab: the same pass on a slab whose v counts as all zeros (the coarse error    */ \
     /* at the start of a cycle): v is not read, no ghost plane is needed; boundary entries must be 0   */ \
     int mgx3dxs_relax_zero_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy,      \

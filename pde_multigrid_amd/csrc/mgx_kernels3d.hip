@@ -111,7 +111,9 @@ template <class real, int TYW, int R, int ABL = 0>
 __global__ void __launch_bounds__(64 * TYW)
     relax3d_xs_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                       int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
-                      int xcd_mode) {
+                      int xcd_mode, int nz1 = 0x7fffffff, int zbeg2 = 0, int zend2 = 0) {
+    // nz1, [zbeg2, zend2): a SECOND range of planes in the same launch (the two edge planes of a z-slab, which the neighbours wait
+    // for: one launch instead of two) -- the z-chunks from number nz1 on belong to it
     const Geo<XSplit, real> g(sx, sy);
     const int H = g.H;
     const int M = (sx + 1) >> 1;  // entries of the even-x half (the odd-x half has M-1)
@@ -150,6 +152,11 @@ __global__ void __launch_bounds__(64 * TYW)
     // planes [zbeg, zend) of the local array are updated (1 .. sz-2 for a whole grid; the owned planes of
     // a z-slab, whose neighbours below / above are ghost planes); `colour` already includes the parity of
     // the slab's global z offset
+    if (bz >= nz1) {
+        bz -= nz1;
+        zbeg = zbeg2;
+        zend = zend2;
+    }
     const int z0 = zbeg + bz * zchunk;
     const int z1 = min(z0 + zchunk, zend);
     if (z0 >= z1) return;
@@ -2218,6 +2225,23 @@ static void relax3d_xs_pass(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
     }
 }
 
+// one colour pass over TWO short runs of planes [zb1, ze1) and [zb2, ze2) in ONE launch of relax3d_xs_kernel (the bottom and the top
+// edge of a z-slab: a middle rank relaxes them first, in front of its ghost exchange); false = not taken (a run of 8 or more planes:
+// the caller makes two passes)
+template <class real>
+static bool relax3d_xs_pass2(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zb1, int ze1, int zb2, int ze2, real hx2, real hy2,
+                             real hz2, int colour) {
+    if (!ctx->slab_edges_merged || ze1 <= zb1 || ze2 <= zb2 || ze1 - zb1 >= 8 || ze2 - zb2 >= 8 || sx < 3 || sy < 3) return false;
+    constexpr int TYW = 4, R = 4;
+    const int zchunk = 1;
+    const int M = (sx + 1) / 2;
+    const int gx = ceil_div(M - 1, 64), gy = ceil_div(sy - 2, TYW * R), gz1 = ze1 - zb1, gz2 = ze2 - zb2;
+    note_relax_kernel<real>(ctx, "relax3d_xs_kernel", TYW, R, 0);
+    hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3((unsigned)gx * gy * (gz1 + gz2)), dim3(64, TYW, 1), 0, ctx->compute, (const real*)v, v, f,
+                       sx, sy, zb1, ze1, hx2, hy2, hz2, colour, zchunk, gx, gy, 0, gz1, zb2, ze2);
+    return true;
+}
+
 // `ncycles` red-black sweeps = 2*ncycles colour passes.  On large levels the passes are time-skewed over
 // z-slabs ("wavefront" order): slab by slab, pass s runs on the planes [a-s, a+B-s) right after pass s-1 ran
 // on [a-s+1, a+B-s+1).  Pass s at plane z needs pass s-1 only at planes z-1, z, z+1, so every point still sees
@@ -2688,6 +2712,25 @@ int relax3d_colour_slab(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, co
                 "relax_colour_slab: bad colour / plane range");
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
     relax3d_xs_pass<real>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, (colour + zoff) & 1);
+    MGX_LAUNCH_CHECK();
+    return MGX_OK;
+}
+
+// the same for the two edges of a slab, local planes [zb1, ze1) and [zb2, ze2), in one launch where both are short
+template <class real>
+int relax3d_colour_slab2(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, const real h[3], int colour, int zb1, int ze1, int zb2,
+                         int ze2, int zoff) {
+    MGX_REQUIRE(ctx && v && f && h, MGX_ERR_INVALID, "relax_colour_slab2: NULL argument");
+    MGX_USE(ctx);
+    MGX_REQUIRE(valid_size(sx) && valid_size(sy), MGX_ERR_SIZE, "relax_colour_slab2: sizes %d x %d are not 2^k+1", sx, sy);
+    MGX_REQUIRE((colour == 0 || colour == 1) && zb1 >= 1 && ze1 >= zb1 && zb2 >= ze1 && ze2 >= zb2 && zoff >= 0, MGX_ERR_INVALID,
+                "relax_colour_slab2: bad colour / plane ranges");
+    const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
+    const int c = (colour + zoff) & 1;
+    if (!relax3d_xs_pass2<real>(ctx, v, f, sx, sy, zb1, ze1, zb2, ze2, hx2, hy2, hz2, c)) {
+        relax3d_xs_pass<real>(ctx, v, f, sx, sy, zb1, ze1, hx2, hy2, hz2, c);
+        relax3d_xs_pass<real>(ctx, v, f, sx, sy, zb2, ze2, hx2, hy2, hz2, c);
+    }
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -3173,6 +3216,10 @@ template int relax3d_xs_from_zero<double>(mgx_ctx*, double*, const double*, cons
                                         int colour, int zbeg, int zend, int zoff) {                              \
         return mgx::relax3d_colour_slab<real>(ctx, v, f, sx, sy, h, colour, zbeg, zend, zoff);                   \
     }                                                                                                            \
+    int mgx3dxs_relax_colour_slab2_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, const real h[3],  \
+                                         int colour, int zb1, int ze1, int zb2, int ze2, int zoff) {             \
+        return mgx::relax3d_colour_slab2<real>(ctx, v, f, sx, sy, h, colour, zb1, ze1, zb2, ze2, zoff);          \
+    }                                                                                                            \
     int mgx3dxs_relax_zero_colour_slab_##SFX(mgx_ctx* ctx, real* v, const real* f, int sx, int sy,               \
                                              const real h[3], int colour, int zbeg, int zend, int zoff) {        \
         return mgx::relax3d_zero_colour_slab<real>(ctx, v, f, sx, sy, h, colour, zbeg, zend, zoff);              \
@@ -3353,6 +3400,9 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "relax3d.resident")) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "set_param: relax3d.resident = %d not in {0, 1, 2}", value);
         ctx->relax_resident = value;
+    } else if (!strcmp(name, "slab.edges_merged")) {
+        MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: slab.edges_merged = %d not in {0, 1}", value);
+        ctx->slab_edges_merged = value;  // the two edge planes of a z-slab in one launch (mgx3dxs_relax_colour_slab2_*) or in two
     } else if (!strcmp(name, "relax3d.resident_tile")) {
         MGX_REQUIRE(value == 0 || value == 8, MGX_ERR_INVALID, "set_param: relax3d.resident_tile = %d not in {0, 8}", value);
         ctx->resident_tile = value;

@@ -48,6 +48,8 @@ modes = ((None, "library default (inline_bytes = 96 MB)"), (0, "every level over
 for inline_bytes, label in ((modes[0], modes[3]) if only_rank >= 0 else modes):
     for vr in ((only_rank,) if only_rank >= 0 else (0, nranks // 2, nranks - 1)):
         ctx = P.Context(0)
+        for kv in filter(None, os.environ.get("MGX_PARAMS", "").split(",")):  # e.g. MGX_PARAMS=slab.edges_merged=0
+            ctx.set_param(kv.split("=")[0], int(kv.split("=")[1]))
         ctx.comm_init_rehearsal(P.Context.unique_id(), vr, nranks)
         mg = P.DistMultiGrid3D(ctx, [n] * 3, R3, np.float64, min_planes=32, inline_bytes=None if inline_bytes == -1 else inline_bytes,
                                use_graph=inline_bytes == -1)
