@@ -3,7 +3,7 @@
 by hand on the GPU box, not part of the suites): random anisotropic 2^k+1 shapes, sweep counts, level counts, residual
 modes, both precisions, V-cycles and FMG, boxes with and without power-of-two spacings.
 
-    python3 tools/fuzz_cycles.py [cases] [seed]
+    python3 tests/checkers/fuzz_cycles.py [cases] [seed]
 MGX_PARAMS=name=value,... sets library parameters first (e.g. rr3d.black=2,relax3d.resident_min=1: the fused way down and
 the resident Relax kernel on every level that has the geometry); MGX_FUZZ_SWEEPS=n: sweep counts up to n - 1 (default 4).
 """
@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle as O  # noqa: E402

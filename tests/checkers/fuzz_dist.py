@@ -2,14 +2,14 @@
 """One-off fuzz of the z-slab driver (thread-ranks on one GPU over the asynchronous test transport, delay hook on) against
 the single-GPU hierarchy: random shapes, rank counts, agglomeration thresholds, sweep counts, modes, V-cycles and FMG.
 
-    python3 tools/fuzz_dist.py [cases] [seed]
+    python3 tests/checkers/fuzz_dist.py [cases] [seed]
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -3,13 +3,13 @@
 points per row, sweep counts 1 ... 40, both precisions, plain and from-zero calls, all three forms ("relax3d.resident" 1 / 2,
 "relax3d.resident_tile" 0 / 8) interleaved on ONE context, so that exchange-buffer lay-outs, launch epochs and tags of one form
 meet those of the others.
-    python3 tools/resident_soak.py [cases] [seed]"""
+    python3 tests/checkers/resident_soak.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle as O  # noqa: E402
