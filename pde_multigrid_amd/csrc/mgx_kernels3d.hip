@@ -2210,6 +2210,13 @@ static void relax3d_xs_pass(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
     if (zend <= zbeg || sx < 3 || sy < 3) return;
     if (ctx->relax_lds != 0 && relax3d_xs_pass_lds<real>(ctx, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour)) return;
     int ty = ctx->relax_ty, rows = ctx->relax_rows, zchunk = ctx->relax_zchunk;
+    // levels of 129-point rows (one wave wide), fp64, library defaults: eight waves of two rows, runs of two planes -- 14.9 against 16.0 us
+    // per sweep at 129^3 (tools/sweep_relax.py --n 129; the shapes differ by a few per cent, the level is latency, not bytes)
+    if (sizeof(real) == 8 && (sx + 1) / 2 - 1 == 64 && sy - 2 >= 64 && zend - zbeg >= 16 && ty == 4 && rows == 4 && zchunk <= 0) {
+        ty = 8;
+        rows = 2;
+        zchunk = 2;
+    }
     while (rows > 1 && rows * ty > sy - 2) rows >>= 1;  // small levels: do not idle most of a block
     while (ty > 1 && rows * ty > sy - 2) ty >>= 1;
     if (zchunk <= 0) {
