@@ -19,10 +19,13 @@ Workload
 One step = one VCycle(0, 2, 2) through the C host layer (include/mg_multigrid.h), inputs resident in HBM.
     MLUPS = (v1+v2) * sum_levels (n_l - 2)^3 * steps / seconds          
     The K steps are timed BATCHES times (default 5; each batch = exactly K steps between a barrier + sync on both sides,
-    maximum over ranks); `value` / `ms_per_step` are the MEDIAN batch, `batches` lists them all.
+    maximum over ranks); `value` / `ms_per_step` are the MEDIAN batch, `batches` lists them all.  W untimed cycles come first
+    (default 150 = 0.5 s at 513^3: the GPU needs ~100 cycles to reach its steady state, the first ones run 2-3 % slower).
 secondary (N = 1, default size only): BASELINE configs[1] (2D Lyapunov 1025^2, 7 levels, fp64), configs[2] (3D 257^3, 6
     levels, fp64) and the headline workload in the reference's own precision (513^3 fp32), each timed the same way and
-    checked against its committed known answer.
+    checked against its committed known answer; and the reference's two PUBLISHED GPU workloads with their own parameters
+    (3D FMG(2,3000,3000) at 129^3, 2D Lyapunov FMG(2,500,500) at 4097^2; whole programs, fp32), checked
+    the same way.
 roofline: the dominant kernel is the red-black Gauss-Seidel smoother on the finest level; its algorithmic
     traffic is 3 reals per lattice update per red+black sweep = 24 B/LUP in fp64 (12 B per LUP of one colour
     launch).  `achieved` = algorithmic bytes per launch / average launch duration, measured here with HIP events
@@ -229,7 +232,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=150,
+                    help="untimed cycles first; the default covers the GPU's ramp-up: at 513^3 the first ~100 cycles (0.3 s) run 2-3 %% slower "
+                         "than the steady state (batches with --warmup 3: 3.27, 3.25, 3.26, 3.22, 3.19 ms; with 100: 3.165 +- 0.003)")
     ap.add_argument("--size", dest="n", type=int, default=0, help="points per axis of the finest grid (2^k+1); 0 = 513 (N=1) / 1025 (N>1)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--v1", type=int, default=2)
