@@ -438,6 +438,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
     const double rd = relax3d_rd<real>(hx2, hy2, hz2);  // fp32: the division by multiplication (relax3d_point_rd)
     static_assert(!CORR || R == 2, "the correcting variant is written for 2 rows per lane");
     static_assert(!CORR || (WX * WY >= WY * R / 2 + 2 && WY > 1), "one wave per coarse row under the tile and its rim");
+    static_assert(!CORR || WX >= 2, "a wave of the correcting variant has at most one rim (left or right)");
     constexpr int KR = WY * R / 2 + 1, KC = 64 * WX + 2;  // coarse rows / columns staged per plane (column 0: left of the tile, unused)
     __shared__ real ey[2][WY][WX][2][64];
     __shared__ real ex[2][WY][WX][2][R];
@@ -501,11 +502,16 @@ __global__ void __launch_bounds__(64 * WX * WY)
     // values belong to (the set P: cell rows py % (WY R / 2) == 0, cell columns i > 0 with i % (64 WX) in {0, 64 WX - 1};
     // about 1/8 of the cells) are corrected IN PLACE by correct_pset3d_xs_kernel before this pass; own entries in P are
     // taken as they are.
-    bool own[R];  // does row r's own entry get the correction on the fly?
+    // (Round 3, end: only the ROWS are in P now.  The pair a tile reads left / right of itself is ONE value per row and step, in one
+    // lane of the wave: that lane corrects it on the fly from the staged tile's outer columns -- one interpolation per wave and step,
+    // hidden behind the loads -- and the column part of the pre-pass, 47 us at 513^3 for 12 MB of useful data in 128-byte lines, is gone.)
+    bool own[R];   // does row r's own entry get the correction on the fly?
+    bool rimc[R];  // does the value this lane takes from the neighbouring tile in row r (rimL: x = 2j - 1, rimR: x = 2j + 2) get one?
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const bool inP = (wy == 0 && r == 0) || (wy == WY - 1 && r == R - 1) || (j > 0 && j % (64 * WX) == 0) || (j % (64 * WX) == 64 * WX - 1);
+        const bool inP = (wy == 0 && r == 0) || (wy == WY - 1 && r == R - 1);
         own[r] = CORR && lane_on && !inP && y0 + r <= sy - 2;
+        rimc[r] = CORR && lane_on && !inP && y0 + r <= sy - 2 && ((lane == 0 && wx == 0 && j > 0) || (lane == 63 && wx == WX - 1 && j + 1 < M - 1));
     }
     // request coarse plane `plane` (kt), store what was requested into its ring slot
 #define MGX_K_REQUEST(plane)                                                                    \
@@ -539,6 +545,30 @@ __global__ void __launch_bounds__(64 * WX * WY)
             case 1: e0 = interpolate3d_point<real>(0, 1, 1, g0_); e1 = interpolate3d_point<real>(1, 0, 1, g1_); break; \
             case 2: e0 = interpolate3d_point<real>(1, 1, 0, g0_); e1 = interpolate3d_point<real>(0, 0, 0, g1_); break; \
             default: e0 = interpolate3d_point<real>(1, 1, 1, g0_); e1 = interpolate3d_point<real>(0, 0, 1, g1_); break; \
+        }                                                                                                           \
+    } while (0)
+
+    // the correction e of the value the wave's rim lane takes from the neighbouring tile at plane zz, in the ONE row rr whose parity
+    // asks for it (left rim, wave column 0: rows with q_r = 0, the point x = 2j - 1 of coarse column j - 1, odd; right rim, last wave
+    // column: rows with q_r = 1, x = 2j + 2 = coarse column j + 1, even); all wave-uniform but the lane, so every lane computes it and
+    // the rim lane uses it.  qq = the parity of row 0 at plane zz.
+#define MGX_CORR_RIM(qq, zz, rr, e)                                                                                  \
+    do {                                                                                                            \
+        const real* k0_ = &sK[0][0][0] + ((zz) >> 1) % 3 * (KR * KC) + kmy;                                         \
+        const real* k1_ = &sK[0][0][0] + (((zz) >> 1) + 1) % 3 * (KR * KC) + kmy;                                   \
+        const bool left_ = wx == 0;                                                                                 \
+        rr = left_ ? ((qq) & 1) : 1 - ((qq) & 1);  /* q_r = qq ^ (r & 1): 0 for the left rim, 1 for the right */     \
+        const int co_ = (left_ ? -1 : 1) + (rr) * KC;                                                               \
+        auto g_ = [&](int dx, int dy, int dz) { return (dz ? k1_ : k0_)[co_ + dy * KC + dx]; };                     \
+        switch ((left_ ? 4 : 0) + (rr) * 2 + ((zz) & 1)) { /* (x parity, y parity = 1 - rr, z parity) as literals */  \
+            case 0: e = interpolate3d_point<real>(0, 1, 0, g_); break;                                              \
+            case 1: e = interpolate3d_point<real>(0, 1, 1, g_); break;                                              \
+            case 2: e = interpolate3d_point<real>(0, 0, 0, g_); break;                                              \
+            case 3: e = interpolate3d_point<real>(0, 0, 1, g_); break;                                              \
+            case 4: e = interpolate3d_point<real>(1, 1, 0, g_); break;                                              \
+            case 5: e = interpolate3d_point<real>(1, 1, 1, g_); break;                                              \
+            case 6: e = interpolate3d_point<real>(1, 0, 0, g_); break;                                              \
+            default: e = interpolate3d_point<real>(1, 0, 1, g_); break;                                             \
         }                                                                                                           \
     } while (0)
 
@@ -589,6 +619,8 @@ __global__ void __launch_bounds__(64 * WX * WY)
         op[r] = 0;
     }
     MGX_LOAD_RIM(0, q, xc, Nc, Sc);
+    real er0 = 0;  // CORR: the correction of the rim value of plane z0 + 1 (row rr0)
+    int rr0 = 0;
     if constexpr (CORR) {
         // own entries of the planes z0-1, z0, z0+1: the correction straight from the coarse array, once per run of planes
 #pragma unroll
@@ -599,6 +631,17 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 if ((1 - qr) | j) cc[r] = cc[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + 1 - qr, y, z0);
                 if (z0 + 1 <= szg - 2 && (qr | j)) cu[r] = cu[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + qr, y, z0 + 1);
             }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (rimc[r]) {  // the neighbouring tile's value of plane z0 (z0 >= 1 is an interior plane)
+                const int qr = q ^ (r & 1);
+                if (qr == 0 && lane == 0) xc[r] = xc[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j - 1, y0 + r, z0);
+                if (qr == 1 && lane == 63) xc[r] = xc[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + 2, y0 + r, z0);
+            }
+        // ... and of plane z0 + 1, which arrives in the first step: one of its two coarse planes is not staged yet (z0 even)
+        rr0 = wx == 0 ? ((q ^ 1) & 1) : 1 - ((q ^ 1) & 1);
+        if (rimc[rr0] && z0 + 1 <= szg - 2)
+            er0 = interp_xs_at<real>(coarse, CH, CP, CPL, wx == 0 ? 2 * j - 1 : 2 * j + 2, y0 + rr0, z0 + 1);
         // the coarse planes under the arrivals of the first three steps (the loop's requests start with the fourth)
         MGX_K_REQUEST(min((z0 + 2) >> 1, ckmax));
         MGX_K_STORE((z0 + 2) >> 1);
@@ -691,11 +734,20 @@ __global__ void __launch_bounds__(64 * WX * WY)
             en[r] = 0;
             dc[r] = false;
         }
+        real er = 0;  // CORR: the correction of the rim value that is on its way (plane z + 1, row rrim) ...
+        int rrim = 0;
         if constexpr (CORR) {
             if (more) {
                 MGX_CORR_PAIR(q ^ 1, z + 2, en[0], en[1]);  // all lanes: the staged tile covers every lane's cell
 #pragma unroll
                 for (int r = 0; r < R; r++) dc[r] = own[r] && z + 2 <= szg - 2 && ((q ^ 1 ^ (r & 1)) | j);
+                if (z == z0) {
+                    er = er0;
+                    rrim = rr0;
+                } else if (wx == 0 || wx == WX - 1) {
+                    MGX_CORR_RIM(q ^ 1, z + 1, rrim, er);
+                }
+                if (z + 1 > szg - 2) er = 0;  // a boundary plane: no correction
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -713,7 +765,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
             cc[r] = cu[r];
             cu[r] = dc[r] ? cn[r] + en[r] : cn[r];
             fc[r] = fn[r];
-            xc[r] = xn[r];
+            xc[r] = (CORR && rimc[r] && r == rrim) ? xn[r] + er : xn[r];
             op[r] = oc[r];
         }
         if constexpr (CORR) {
@@ -742,6 +794,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
 #undef MGX_K_REQUEST
 #undef MGX_K_STORE
 #undef MGX_CORR_PAIR
+#undef MGX_CORR_RIM
 }
 
 // ------------------------------------------------------------------ relax, one colour, XSplit, pipelined, TWO pairs per lane
@@ -2894,7 +2947,9 @@ static void corr_pset_launch(mgx_ctx* ctx, real* v, int sx, int sy, int fzoff, c
     const int nk = (cn[1] - 2) / PH + 1;
     hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ceil_div(M - 1, 64), ceil_div(nk, 4), pzend - pzbeg), blk(), 0, ctx->compute, v,
                        sx, sy, coarse_v, cn[0], cn[1], PW, PH, 0, fzoff, czoff, pzbeg, zmin, zmax);
-    const int ncol = 2 * ((M - 1) / PW);
+    // the column part: only for the two-pairs-per-lane kernel (fp32, PW = 256); relax3d_xs_pipe_kernel<.., 2> corrects the values it
+    // takes from the neighbouring tile itself
+    const int ncol = PW == 256 ? 2 * ((M - 1) / PW) : 0;
     if (ncol > 0)
         hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ncol, ceil_div(cn[1] - 1, 256), pzend - pzbeg), blk(), 0, ctx->compute, v, sx,
                            sy, coarse_v, cn[0], cn[1], PW, PH, 1, fzoff, czoff, pzbeg, zmin, zmax);
