@@ -879,11 +879,15 @@ __global__ void __launch_bounds__(64 * WX * WY)
     for (int a = 0; a <= NK; a++) kt[a] = 0;
     const int kmy = wy * (R / 2) * KC + wx * 128 + 2 * lane + 1;  // coarse cell (column j0, row (y0 - 1) / 2); the second pair's: + 1
     bool own0[R], own1[R];  // does the entry of pair j0 / j0 + 1 in row r get its correction on the fly (not in the set P)?
+    bool rimc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const bool rowP = (wy == 0 && r == 0) || (wy == WY - 1 && r == R - 1);
-        own0[r] = CORR && lane_on && !rowP && !(j0 > 0 && j0 % (128 * WX) == 0) && y0 + r <= sy - 2;
-        own1[r] = CORR && lane_on && !rowP && (j0 + 1) % (128 * WX) != 128 * WX - 1 && y0 + r <= sy - 2;
+        own0[r] = CORR && lane_on && !rowP && y0 + r <= sy - 2;
+        own1[r] = CORR && lane_on && !rowP && y0 + r <= sy - 2;
+        // the value taken from the neighbouring tile (left: x = 2 j0 - 1, right: x = 2 j0 + 4) is corrected by the lane that reads
+        // it, as in relax3d_xs_pipe_kernel: no tile-edge columns in the set P
+        rimc[r] = CORR && lane_on && !rowP && y0 + r <= sy - 2 && ((lane == 0 && wx == 0 && j0 > 0) || (lane == 63 && wx == WX - 1 && j0 + 2 < M - 1));
     }
 #define MGX_K2_REQUEST(plane)                                                                   \
     do {                                                                                        \
@@ -912,6 +916,25 @@ __global__ void __launch_bounds__(64 * WX * WY)
             case 1: e0 = interpolate3d_point<real>(0, 1, 1, g0_); e1 = interpolate3d_point<real>(1, 0, 1, g1_); break; \
             case 2: e0 = interpolate3d_point<real>(1, 1, 0, g0_); e1 = interpolate3d_point<real>(0, 0, 0, g1_); break; \
             default: e0 = interpolate3d_point<real>(1, 1, 1, g0_); e1 = interpolate3d_point<real>(0, 0, 1, g1_); break; \
+        }                                                                                                           \
+    } while (0)
+#define MGX_CORR_RIM2(qq, zz, rr, e)                                                                                 \
+    do {                                                                                                            \
+        const real* k0_ = &sK[0][0][0] + ((zz) >> 1) % 3 * (KR * KC) + kmy;                                         \
+        const real* k1_ = &sK[0][0][0] + (((zz) >> 1) + 1) % 3 * (KR * KC) + kmy;                                   \
+        const bool left_ = wx == 0;                                                                                 \
+        rr = left_ ? ((qq) & 1) : 1 - ((qq) & 1);                                                                   \
+        const int co_ = (left_ ? -1 : 2) + (rr) * KC;                                                               \
+        auto g_ = [&](int dx, int dy, int dz) { return (dz ? k1_ : k0_)[co_ + dy * KC + dx]; };                     \
+        switch ((left_ ? 4 : 0) + (rr) * 2 + ((zz) & 1)) {                                                          \
+            case 0: e = interpolate3d_point<real>(0, 1, 0, g_); break;                                              \
+            case 1: e = interpolate3d_point<real>(0, 1, 1, g_); break;                                              \
+            case 2: e = interpolate3d_point<real>(0, 0, 0, g_); break;                                              \
+            case 3: e = interpolate3d_point<real>(0, 0, 1, g_); break;                                              \
+            case 4: e = interpolate3d_point<real>(1, 1, 0, g_); break;                                              \
+            case 5: e = interpolate3d_point<real>(1, 1, 1, g_); break;                                              \
+            case 6: e = interpolate3d_point<real>(1, 0, 0, g_); break;                                              \
+            default: e = interpolate3d_point<real>(1, 0, 1, g_); break;                                             \
         }                                                                                                           \
     } while (0)
 #define MGX_LD2(p, i) (*(const vec2*)&(p)[(i)])
@@ -965,11 +988,17 @@ __global__ void __launch_bounds__(64 * WX * WY)
         cn[r] = fn[r] = oc[r] = vec2{0, 0};
     }
     MGX_LOAD_RIM2(0, q, xc, Nc, Sc);
+    real er0 = 0;
+    int rr0 = 0;
     if constexpr (CORR) {
         // own entries of the planes z0-1, z0, z0+1: the correction straight from the coarse array, once per run of planes
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int qr = q ^ (r & 1), y = y0 + r;
+            if (rimc[r]) {
+                if (qr == 0 && lane == 0) xc[r] = xc[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 - 1, y, z0);
+                if (qr == 1 && lane == 63) xc[r] = xc[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + 4, y, z0);
+            }
             if (own0[r]) {
                 if (z0 - 1 >= 1 && (qr | j0)) cp[r].x = cp[r].x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + qr, y, z0 - 1);
                 if ((1 - qr) | j0) cc[r].x = cc[r].x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + 1 - qr, y, z0);
@@ -981,6 +1010,9 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 if (z0 + 1 <= szg - 2) cu[r].y = cu[r].y + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + qr, y, z0 + 1);
             }
         }
+        rr0 = wx == 0 ? ((q ^ 1) & 1) : 1 - ((q ^ 1) & 1);
+        if (rimc[rr0] && z0 + 1 <= szg - 2)
+            er0 = interp_xs_at<real>(coarse, CH, CP, CPL, wx == 0 ? 2 * j0 - 1 : 2 * j0 + 4, y0 + rr0, z0 + 1);
         // the coarse planes under the arrivals of the first three steps (the loop's requests start with the fourth)
         MGX_K2_REQUEST(min((z0 + 2) >> 1, ckmax));
         MGX_K2_STORE((z0 + 2) >> 1);
@@ -1044,6 +1076,8 @@ __global__ void __launch_bounds__(64 * WX * WY)
             en0[r] = en1[r] = 0;
             dc0[r] = dc1[r] = false;
         }
+        real er = 0;
+        int rrim = 0;
         if constexpr (CORR) {
             if (more) {
                 MGX_CORR_PAIR2(kmy, q ^ 1, z + 2, en0[0], en0[1]);
@@ -1053,6 +1087,13 @@ __global__ void __launch_bounds__(64 * WX * WY)
                     dc0[r] = own0[r] && z + 2 <= szg - 2 && ((q ^ 1 ^ (r & 1)) | j0);
                     dc1[r] = own1[r] && z + 2 <= szg - 2;
                 }
+                if (z == z0) {
+                    er = er0;
+                    rrim = rr0;
+                } else if (wx == 0 || wx == WX - 1) {
+                    MGX_CORR_RIM2(q ^ 1, z + 1, rrim, er);
+                }
+                if (z + 1 > szg - 2) er = 0;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1071,7 +1112,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
             cu[r].x = dc0[r] ? cn[r].x + en0[r] : cn[r].x;
             cu[r].y = dc1[r] ? cn[r].y + en1[r] : cn[r].y;
             fc[r] = fn[r];
-            xc[r] = xn[r];
+            xc[r] = (CORR && rimc[r] && r == rrim) ? xn[r] + er : xn[r];
             op[r] = oc[r];
         }
         if constexpr (CORR) {
@@ -1090,6 +1131,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
 #undef MGX_K2_REQUEST
 #undef MGX_K2_STORE
 #undef MGX_CORR_PAIR2
+#undef MGX_CORR_RIM2
 }
 
 // ------------------------------------------------------------------ relax, whole small level in one workgroup
@@ -2947,12 +2989,8 @@ static void corr_pset_launch(mgx_ctx* ctx, real* v, int sx, int sy, int fzoff, c
     const int nk = (cn[1] - 2) / PH + 1;
     hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ceil_div(M - 1, 64), ceil_div(nk, 4), pzend - pzbeg), blk(), 0, ctx->compute, v,
                        sx, sy, coarse_v, cn[0], cn[1], PW, PH, 0, fzoff, czoff, pzbeg, zmin, zmax);
-    // the column part: only for the two-pairs-per-lane kernel (fp32, PW = 256); relax3d_xs_pipe_kernel<.., 2> corrects the values it
-    // takes from the neighbouring tile itself
-    const int ncol = PW == 256 ? 2 * ((M - 1) / PW) : 0;
-    if (ncol > 0)
-        hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ncol, ceil_div(cn[1] - 1, 256), pzend - pzbeg), blk(), 0, ctx->compute, v, sx,
-                           sy, coarse_v, cn[0], cn[1], PW, PH, 1, fzoff, czoff, pzbeg, zmin, zmax);
+    // no column part any more: both correcting kernels correct the values they take from the neighbouring tile themselves
+    (void)M;
 }
 
 // the red pass through the correction over the LOCAL planes [zb, ze) of v: `coarse_sh` = the coarse array shifted so that

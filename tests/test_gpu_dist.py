@@ -151,6 +151,23 @@ def test_dist_correction_read_on_the_fly_on_slabs(nranks, inline_bytes, v2):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("nranks,n3,min_planes,params", [(2, [257, 257, 17], 8, None), (2, [257, 257, 17], 8, {"rr3d.black": 2}),
+                                                         (4, [257, 129, 33], 8, None), (8, [257, 129, 65], 8, {"rr3d.black": 2})])
+def test_dist_every_rank_takes_the_same_form_of_an_operator(nranks, n3, min_planes, params):
+    """slabs of exactly 8 planes: the last rank updates one plane less than the others (its top plane is the boundary), which is below
+    the minimum of the correcting pass -- the choice between the forms of an operator (which differ in what they exchange) must not
+    depend on the rank's own plane count (found by tests/checkers/fuzz_dist.py: rank 0 waited for a ghost plane rank 1 never sent)"""
+    rng = np.random.default_rng(nranks + n3[2])
+    rg = [0, 1, 0, 1, 0, 1]
+    v0 = rng.uniform(-1, 1, O.shape(n3))
+    f0 = rng.uniform(-1, 1, O.shape(n3))
+    for inline_bytes in (0, None):
+        got, info = run_ranks(nranks, n3, rg, np.float64, 2, 2, 2, min_planes, mode=P.CORRECT, v0=v0, f0=f0, inline_bytes=inline_bytes, params=params)
+        want = O.cycle3d(n3, rg, mode=0, v1=2, v2=2, reps=2, v=v0, f=f0, residual_mode=P.CORRECT, dtype=np.float64)
+        assert bits_equal(got, want)
+
+
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("nranks,v1,dtype", [(1, 2, np.float64), (2, 1, np.float64), (2, 2, np.float32), (4, 2, np.float64), (8, 1, np.float64),
                                              (8, 3, np.float32)])
 def test_dist_last_black_pass_inside_residual_restrict_on_slabs(nranks, v1, dtype):
