@@ -437,9 +437,9 @@ __global__ void __launch_bounds__(64 * WX * WY)
     constexpr bool ZERO1 = VAR == 3;
     const double rd = relax3d_rd<real>(hx2, hy2, hz2);  // fp32: the division by multiplication (relax3d_point_rd)
     static_assert(!CORR || R == 2, "the correcting variant is written for 2 rows per lane");
-    static_assert(!CORR || (WX * WY >= WY * R / 2 + 2 && WY > 1), "one wave per coarse row under the tile and its rim");
+    static_assert(!CORR || (WX * WY >= WY * R / 2 + 2 && WY > 1), "one wave per staged coarse row; a wave has at most one edge row (above or below)");
     static_assert(!CORR || WX >= 2, "a wave of the correcting variant has at most one rim (left or right)");
-    constexpr int KR = WY * R / 2 + 1, KC = 64 * WX + 2;  // coarse rows / columns staged per plane (column 0: left of the tile, unused)
+    constexpr int KR = WY * R / 2 + 2, KC = 64 * WX + 2;  // coarse rows / columns staged per plane: the cells under the tile and one more on every side
     __shared__ real ey[2][WY][WX][2][64];
     __shared__ real ex[2][WY][WX][2][R];
     __shared__ real sK[CORR ? 3 : 1][CORR ? KR : 1][CORR ? KC : 1];
@@ -509,10 +509,13 @@ __global__ void __launch_bounds__(64 * WX * WY)
     bool rimc[R];  // does the value this lane takes from the neighbouring tile in row r (rimL: x = 2j - 1, rimR: x = 2j + 2) get one?
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const bool inP = (wy == 0 && r == 0) || (wy == WY - 1 && r == R - 1);
-        own[r] = CORR && lane_on && !inP && y0 + r <= sy - 2;
-        rimc[r] = CORR && lane_on && !inP && y0 + r <= sy - 2 && ((lane == 0 && wx == 0 && j > 0) || (lane == 63 && wx == WX - 1 && j + 1 < M - 1));
+        own[r] = CORR && lane_on && y0 + r <= sy - 2;
+        rimc[r] = CORR && lane_on && y0 + r <= sy - 2 && ((lane == 0 && wx == 0 && j > 0) || (lane == 63 && wx == WX - 1 && j + 1 < M - 1));
     }
+    // ... and, last, the ROWS: the row a tile reads above / below itself (wave row 0: y0 - 1, the last wave row: y0 + R) is one value
+    // per lane and step in the edge waves, corrected there from the staged rows (one more is staged for it); with that the set P is
+    // empty and the pre-pass is gone for this kernel
+    const bool edgeN = CORR && lane_on && wy == 0 && y0 - 1 >= 1, edgeS = CORR && lane_on && wy == WY - 1 && y0 + R <= sy - 2;
     // request coarse plane `plane` (kt), store what was requested into its ring slot
 #define MGX_K_REQUEST(plane)                                                                    \
     do {                                                                                        \
@@ -572,6 +575,30 @@ __global__ void __launch_bounds__(64 * WX * WY)
         }                                                                                                           \
     } while (0)
 
+    // the correction e of the edge-row value of plane zz this lane reads (wave row 0: the row above, y0 - 1, even, the staged row of
+    // the wave's first row; last wave row: the row below, y0 + R, odd, between the next two staged rows); qq = parity of row 0 at zz:
+    // the entry is x = 2j + qq above, x = 2j + (qq ^ 1) below (R = 2)
+#define MGX_CORR_EDGE(qq, zz, e)                                                                                    \
+    do {                                                                                                            \
+        const real* k0_ = &sK[0][0][0] + ((zz) >> 1) % 3 * (KR * KC) + kmy;                                         \
+        const real* k1_ = &sK[0][0][0] + (((zz) >> 1) + 1) % 3 * (KR * KC) + kmy;                                   \
+        const bool below_ = wy != 0;                                                                                \
+        const int xp_ = below_ ? ((qq) ^ 1) & 1 : (qq) & 1;                                                         \
+        const int ro_ = below_ ? KC : 0;                                                                            \
+        auto g_ = [&](int dx, int dy, int dz) { return (dz ? k1_ : k0_)[ro_ + dy * KC + dx]; };                     \
+        switch ((below_ ? 4 : 0) + xp_ * 2 + ((zz) & 1)) {                                                          \
+            case 0: e = interpolate3d_point<real>(0, 0, 0, g_); break;                                              \
+            case 1: e = interpolate3d_point<real>(0, 0, 1, g_); break;                                              \
+            case 2: e = interpolate3d_point<real>(1, 0, 0, g_); break;                                              \
+            case 3: e = interpolate3d_point<real>(1, 0, 1, g_); break;                                              \
+            case 4: e = interpolate3d_point<real>(0, 1, 0, g_); break;                                              \
+            case 5: e = interpolate3d_point<real>(0, 1, 1, g_); break;                                              \
+            case 6: e = interpolate3d_point<real>(1, 1, 0, g_); break;                                              \
+            default: e = interpolate3d_point<real>(1, 1, 1, g_); break;                                             \
+        }                                                                                                           \
+        if (!(xp_ | j)) e = 0; /* x = 0: a boundary entry */                                                        \
+    } while (0)
+
     // everything that comes from memory besides the column itself, for the plane at offset dz from pv, row parity qq.
     // rim-right lanes need index j+1 of half 0 in q_r = 1 rows, rim-left lanes index j-1 of half 1 in q_r = 0 rows
     // (j = 0: x = 0, the result is discarded, index M-1 keeps the load inside the array); in the other rows the lane
@@ -619,7 +646,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
         op[r] = 0;
     }
     MGX_LOAD_RIM(0, q, xc, Nc, Sc);
-    real er0 = 0;  // CORR: the correction of the rim value of plane z0 + 1 (row rr0)
+    real er0 = 0, ee0 = 0;  // CORR: the corrections of the rim value (row rr0) and of the edge-row value of plane z0 + 1
     int rr0 = 0;
     if constexpr (CORR) {
         // own entries of the planes z0-1, z0, z0+1: the correction straight from the coarse array, once per run of planes
@@ -638,6 +665,12 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 if (qr == 0 && lane == 0) xc[r] = xc[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j - 1, y0 + r, z0);
                 if (qr == 1 && lane == 63) xc[r] = xc[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + 2, y0 + r, z0);
             }
+        if (edgeN && (q | j)) Nc = Nc + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + q, y0 - 1, z0);
+        if (edgeS && ((q ^ 1) | j)) Sc = Sc + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + (q ^ 1), y0 + R, z0);
+        if (z0 + 1 <= szg - 2) {
+            if (edgeN && ((q ^ 1) | j)) ee0 = interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + (q ^ 1), y0 - 1, z0 + 1);
+            if (edgeS && (q | j)) ee0 = interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + q, y0 + R, z0 + 1);
+        }
         // ... and of plane z0 + 1, which arrives in the first step: one of its two coarse planes is not staged yet (z0 even)
         rr0 = wx == 0 ? ((q ^ 1) & 1) : 1 - ((q ^ 1) & 1);
         if (rimc[rr0] && z0 + 1 <= szg - 2)
@@ -734,7 +767,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
             en[r] = 0;
             dc[r] = false;
         }
-        real er = 0;  // CORR: the correction of the rim value that is on its way (plane z + 1, row rrim) ...
+        real er = 0, ee = 0;  // CORR: the corrections of the rim value (row rrim) and of the edge-row value that are on their way (plane z + 1)
         int rrim = 0;
         if constexpr (CORR) {
             if (more) {
@@ -744,10 +777,12 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 if (z == z0) {
                     er = er0;
                     rrim = rr0;
-                } else if (wx == 0 || wx == WX - 1) {
-                    MGX_CORR_RIM(q ^ 1, z + 1, rrim, er);
+                    ee = ee0;
+                } else {
+                    if (wx == 0 || wx == WX - 1) MGX_CORR_RIM(q ^ 1, z + 1, rrim, er);
+                    if (wy == 0 || wy == WY - 1) MGX_CORR_EDGE(q ^ 1, z + 1, ee);
                 }
-                if (z + 1 > szg - 2) er = 0;  // a boundary plane: no correction
+                if (z + 1 > szg - 2) er = ee = 0;  // a boundary plane: no correction
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -771,8 +806,8 @@ __global__ void __launch_bounds__(64 * WX * WY)
         if constexpr (CORR) {
             if ((z & 1) && z > z0 && z + 3 < z1) MGX_K_STORE(((z - 1) >> 1) + 3);  // requested in step z - 1
         }
-        Nc = Nn;
-        Sc = Sn;
+        Nc = (CORR && edgeN) ? Nn + ee : Nn;
+        Sc = (CORR && edgeS) ? Sn + ee : Sn;
         if constexpr (ZERO1) {  // what arrived in this step was f: the red values at those places (plane z + 2 / the rim of z + 1)
             const int q1 = q ^ 1;  // the colour's half of row 0 at plane z + 1
 #pragma unroll
@@ -795,6 +830,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
 #undef MGX_K_STORE
 #undef MGX_CORR_PAIR
 #undef MGX_CORR_RIM
+#undef MGX_CORR_EDGE
 }
 
 // ------------------------------------------------------------------ relax, one colour, XSplit, pipelined, TWO pairs per lane
@@ -2987,6 +3023,7 @@ static void corr_pset_launch(mgx_ctx* ctx, real* v, int sx, int sy, int fzoff, c
     const int pzbeg = zmin / 2, pzend = (zmax - 1) / 2 + 1;
     if (pzend <= pzbeg) return;
     const int nk = (cn[1] - 2) / PH + 1;
+    if (PW != 256) return;  // relax3d_xs_pipe_kernel<.., 2> corrects everything it reads itself: its set P is empty
     hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ceil_div(M - 1, 64), ceil_div(nk, 4), pzend - pzbeg), blk(), 0, ctx->compute, v,
                        sx, sy, coarse_v, cn[0], cn[1], PW, PH, 0, fzoff, czoff, pzbeg, zmin, zmax);
     // no column part any more: both correcting kernels correct the values they take from the neighbouring tile themselves
