@@ -353,7 +353,10 @@ int mgx_event_elapsed_ms(mgx_ctx* ctx, mgx_event* start, mgx_event* stop, float*
     /* holds cplanes planes.  corr_fused_takes: 1 when a level with these rows and `nplanes` planes to    */ \
     /* update runs the on-the-fly form.  correct_pset_slab: the tile-edge cells ("set P") of the GLOBAL   */ \
     /* fine planes [zmin, zmax) get v += Interpolate(coarse_v) in place (black points) -- list the ghost  */ \
-    /* planes next to the updated range too, the red pass reads them.  relax_corr_colour_slab: the RED    */ \
+    /* planes next to the updated range too, the red pass reads them.  (Since the end of round 3 the set   */ \
+    /* is EMPTY for the one-pair-per-lane kernel -- fp64, and fp32 rows of < 513 points -- which corrects  */ \
+    /* everything it reads itself: the call is then a no-op; the fp32 two-pair kernel keeps the cell rows.) */ \
+    /* relax_corr_colour_slab: the RED                                                                    */ \
     /* pass over the LOCAL planes [zbeg, zend), every other black value read through the correction; the  */ \
     /* black pass that must follow rewrites every black interior point.                                  */ \
     int mgx3dxs_corr_fused_takes_##SFX(const mgx_ctx* ctx, const int n[3], int nplanes);                \
