@@ -767,6 +767,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
             en[r] = 0;
             dc[r] = false;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         real er = 0, ee = 0;  // CORR: the corrections of the rim value (row rrim) and of the edge-row value that are on their way (plane z + 1)
         int rrim = 0;
         if constexpr (CORR) {
@@ -785,7 +786,6 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 if (z + 1 > szg - 2) er = ee = 0;  // a boundary plane: no correction
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (CORR && kload && more && !(z & 1) && z + 4 < z1) {
             // the staging loads issued last in this step may stay in flight (loads return in order: at most WX + 1
             // outstanding operations means everything issued before them has arrived); they are stored a step later
