@@ -1112,6 +1112,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
             en0[r] = en1[r] = 0;
             dc0[r] = dc1[r] = false;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         real er = 0;
         int rrim = 0;
         if constexpr (CORR) {
@@ -1132,7 +1133,6 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 if (z + 1 > szg - 2) er = 0;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (CORR && kload && more && !(z & 1) && z + 4 < z1) {
             // the staging loads issued last in this step stay in flight (loads return in order: at most NK + 1 outstanding
             // operations means everything issued before them has arrived); they are stored a step later
