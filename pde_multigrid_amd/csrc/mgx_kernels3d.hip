@@ -425,7 +425,7 @@ __device__ __forceinline__ real interp_xs_at(const real* __restrict__ coarse, in
 }
 
 template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0>
-__global__ void __launch_bounds__(64 * WX * WY)
+__global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whatever the shape: 8-wave workgroups run two to a CU
     relax3d_xs_pipe_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                            int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
                            int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0, int ckmax = 0) {
@@ -3058,6 +3058,26 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
                                sy, zb, ze, hx2, hy2, hz2, colour, zchunk, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
         return;
     }
+    if (ctx->corr_low && sizeof(real) == 8) {  // EXPERIMENT: 8-wave workgroups (tiles of 8 rows), two to a CU
+        if (zchunk <= 0) {
+            const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, 8);
+            const int nchunks = max(1, (2 * ctx->num_cus + tiles / 2) / tiles);
+            zchunk = max(8, ceil_div(ze - zb, nchunks));
+        }
+        const int gxl = ceil_div(M - 1, 128), gyl = ceil_div(sy - 2, 8), gzl = ceil_div(ze - zb, zchunk);
+        const bool fntl = (size_t)sx * sy * (size_t)(ze - zb) * sizeof(real) > ((size_t)256 << 20);
+        snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,2,4,2,%s,2>", sizeof(real) == 8 ? "double" : "float",
+                 fntl ? "true" : "false");
+        memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
+        const dim3 gridl((unsigned)gxl * gyl * gzl);
+        if (fntl)
+            hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 4, 2, true, 2>), gridl, dim3(64, 8, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zb,
+                               ze, hx2, hy2, hz2, colour, zchunk, gxl, gyl, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
+        else
+            hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 4, 2, false, 2>), gridl, dim3(64, 8, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zb,
+                               ze, hx2, hy2, hz2, colour, zchunk, gxl, gyl, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
+        return;
+    }
     if (zchunk <= 0) {  // one resident round of 16-wave workgroups as in relax3d_xs_pass_lds
         const int tiles = ceil_div(M - 1, 128) * ceil_div(sy - 2, 16);
         const int target = ctx->num_cus * (sizeof(real) == 4 ? 8 : 1);
@@ -3537,6 +3557,9 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "relax3d.resident")) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "set_param: relax3d.resident = %d not in {0, 1, 2}", value);
         ctx->relax_resident = value;
+    } else if (!strcmp(name, "relax3d.corr_low")) {
+        MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: relax3d.corr_low = %d not in {0, 1}", value);
+        ctx->corr_low = value;  // the correcting red pass in 8-wave workgroups, two to a CU (fp64)
     } else if (!strcmp(name, "slab.edges_merged")) {
         MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: slab.edges_merged = %d not in {0, 1}", value);
         ctx->slab_edges_merged = value;  // the two edge planes of a z-slab in one launch (mgx3dxs_relax_colour_slab2_*) or in two
