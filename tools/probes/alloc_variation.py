@@ -5,6 +5,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pde_multigrid_amd as P
 ctx = P.Context(0)
+for kv in filter(None, os.environ.get("MGX_PARAMS", "").split(",")):
+    ctx.set_param(kv.split("=")[0], int(kv.split("=")[1]))
 e0, e1 = ctx.event(), ctx.event()
 warm = P.MultiGrid3D(ctx, [513] * 3, [0, 1, 0, 1, 0, 1], np.float64, nlevels=1)
 for _ in range(60): warm.Relax(0, 2)
