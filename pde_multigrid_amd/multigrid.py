@@ -854,7 +854,7 @@ class DistMultiGrid3D(_MGBase):
         if inline_bytes is not None:  # None: the library default (mg_multigrid.h); 0: every level overlapped
             self._mg.contents.inline_bytes = int(inline_bytes)
         self._mg.contents.use_graph = int(bool(use_graph))  # opt-in: VCycle(0, ...) captured (RCCL calls included) and replayed
-        if pack_halos is not None:  # None: the library default (half planes behind colour passes when there are neighbours)
+        if pack_halos is not None:  # None: the library default (0 = whole planes)
             self._mg.contents.pack_halos = int(bool(pack_halos))
 
     @property
