@@ -83,6 +83,15 @@ int mgx_ctx_sync(mgx_ctx* ctx);                 /* waits for the compute and com
  * level) has given up on this context -- its workgroups were not resident together; results of that launch are invalid
  * ("relax3d.fused" = 0 / "relax3d.resident" = 0 avoid the kernels).  Meaningful after a synchronisation. */
 int mgx_ctx_check(mgx_ctx* ctx);
+/* After mgx_ctx_check / mgx_ctx_sync reported a given-up wait: the context has stopped launching those kernels (it runs the
+ * colour-pass kernels instead, same results) and keeps reporting the condition until this call clears it.  Synchronises,
+ * resets the hand-off state on the device and the abort word; reenable != 0 also lets the context use the kernels again
+ * (the caller vouches that whatever kept their workgroups from being resident together is gone).  Data written by the
+ * aborted launch stays invalid: upload or recompute it.
+ * These kernels ASSUME the context has the GPU to itself while they run (their grids are sized to be resident at once:
+ * tiles <= CUs x occupancy).  A process that shares the GPU with other contexts or processes sets "gpu.exclusive" to 0
+ * (mgx_ctx_set_param): they are then never launched.  "sync.spin_limit" (default 2^21 polls, ~2 s) bounds every wait. */
+int mgx_ctx_clear_abort(mgx_ctx* ctx, int reenable);
 /* allocates now what some kernels would allocate on first use (the progress words and exchange buffer of the kernels whose
  * workgroups hand data to each other, ~17 MB): the hierarchies call it when they are created, so that their first cycle can
  * be captured into a HIP graph */
@@ -106,6 +115,10 @@ int mgx_ctx_device(const mgx_ctx* ctx, int* device);
  * per pass; "relax3d.resident_tile" 0 (by level) / 8: tiles of 8 x 8 lines always;
  * "rr3d.black" 0 / 1 / 2: the last black pass of the pre-smoothing inside the residual+restrict launch -- off / on the
  * HBM-bound levels / wherever the geometry allows (tests), "rr3d.black_waves" 0 (by precision), 8 (two workgroups per CU), 12, 16 waves per workgroup.
+ * "gpu.exclusive" 1 (default) / 0: 0 = the GPU is shared with other contexts or processes, so the kernels whose workgroups
+ * wait for each other (resident Relax, one-launch sweep of 513-point rows) are never launched; "sync.spin_limit" polls (~1 us
+ * each, default 2^21) before such a wait gives up (see mgx_ctx_check); "test.handoff_fault" != 0 is a TEST HOOK that makes
+ * workgroup 0 of those kernels wait for tags nobody writes (the give-up path under test).
  * Unknown names and out-of-range values are rejected (MGX_ERR_INVALID). */
 int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value);
 /* name (kernel<template arguments>) of the smoother kernel the most recent 3D x-split colour pass launched; "" if none.
@@ -117,6 +130,13 @@ const char* mgx_ctx_last_rr_kernel(const mgx_ctx* ctx);
 /* name of the kernel that ran the correcting red pass (the correction read on the fly) in the most recent
  * mgx3dxs_interpolate_correct_relax_* call; "" when that call corrected in a pass of its own */
 const char* mgx_ctx_last_corr_kernel(const mgx_ctx* ctx);
+/* TEST HOOK, process-wide: on != 0 -> every kernel launch of the library is preceded by a launch that fills the LDS of every
+ * CU with signalling-NaN patterns (a kernel that reads an LDS word before writing it then fails its parity test for certain
+ * instead of depending on the previous launch's leftovers).  Costs ~15 us per launch; results are unchanged by contract. */
+int mgx_test_set_lds_poison(int on);
+/* self-test of the above: one workgroup per CU reads all of its LDS without writing any; *fraction = share of the words
+ * that carry the poison pattern (1.0 with poisoning on: the launch is preceded by the poisoning launch like any other) */
+int mgx_test_lds_probe(mgx_ctx* ctx, double* fraction);
 /* raw hipStream_t of the compute stream (for callers that bring their own HIP code) */
 int mgx_ctx_stream(const mgx_ctx* ctx, void** hip_stream);
 

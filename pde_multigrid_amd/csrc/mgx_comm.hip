@@ -153,7 +153,7 @@ int local_begin(mgx_ctx* ctx, const Peers& peers, const void* to_lower, const vo
     g->cv.notify_all();
     MGX_TRY_RET(wait_posted(g, peers, k, false));
     for (int i = 0; i < peers.n; i++) MGX_HIP(hipStreamWaitEvent(cstream(ctx), g->rank[peers.p[i]].ready[s], 0));
-    if (g->delay_us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, cstream(ctx), (unsigned)g->delay_us);
+    if (g->delay_us > 0) MGX_LAUNCH(delay_kernel, dim3(1), dim3(1), 0, cstream(ctx), (unsigned)g->delay_us);
     *k_out = k;
     return MGX_OK;
 }
@@ -256,7 +256,7 @@ int local_allreduce(mgx_ctx* ctx, double* inout, size_t count) {
         MGX_HIP(hipMemcpyAsync(me.red + (size_t)r * count, src, count * sizeof(double), hipMemcpyDeviceToDevice, cstream(ctx)));
     }
     MGX_TRY_RET(local_end(ctx, peers, k));  // nobody still reads my input: it may be overwritten in place now
-    hipLaunchKernelGGL(sum_ranks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, cstream(ctx), (const double*)me.red,
+    MGX_LAUNCH(sum_ranks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, cstream(ctx), (const double*)me.red,
                        inout, count, ctx->nranks);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(256) halo_halfrows_kernel(const real* __restri
         MGX_REQUIRE(ctx && sx >= 3 && sy >= 3 && (colour == 0 || colour == 1), MGX_ERR_INVALID, "halo_pack: bad argument");  \
         MGX_USE(ctx);                                                                                                        \
         if (ctx->nranks == 1 || ((!plane_a || !stage_a) && (!plane_b || !stage_b))) return MGX_OK;                           \
-        hipLaunchKernelGGL((halo_halfrows_kernel<real>), dim3(sy, 2), dim3(256), 0, ctx->compute, plane_a, stage_a, z_a,     \
+        MGX_LAUNCH((halo_halfrows_kernel<real>), dim3(sy, 2), dim3(256), 0, ctx->compute, plane_a, stage_a, z_a,     \
                            plane_b, stage_b, z_b, sx, sy, colour, 1);                                                        \
         MGX_LAUNCH_CHECK();                                                                                                  \
         return MGX_OK;                                                                                                       \
@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256) halo_halfrows_kernel(const real* __restri
         MGX_USE(ctx);                                                                                                        \
         if (ctx->nranks == 1 || ((!plane_a || !stage_a) && (!plane_b || !stage_b))) return MGX_OK;                           \
         /* behind the receive, on the stream it was enqueued on: mgx_comm_wait covers it */                                  \
-        hipLaunchKernelGGL((halo_halfrows_kernel<real>), dim3(sy, 2), dim3(256), 0, cstream(ctx), stage_a, plane_a, z_a,     \
+        MGX_LAUNCH((halo_halfrows_kernel<real>), dim3(sy, 2), dim3(256), 0, cstream(ctx), stage_a, plane_a, z_a,     \
                            stage_b, plane_b, z_b, sx, sy, colour, 0);                                                        \
         MGX_LAUNCH_CHECK();                                                                                                  \
         return MGX_OK;                                                                                                       \

@@ -30,9 +30,49 @@ int fill_zero(mgx_ctx* ctx, void* dst, size_t bytes) {
     size_t blocks = (n16 + 256 * 8 - 1) / (256 * 8);  // 8 stores per thread
     const size_t cap = (size_t)ctx->num_cus * 32;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->compute, (u32x4*)dst, n16);
+    MGX_LAUNCH(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->compute, (u32x4*)dst, n16);
     MGX_HIP(hipGetLastError());
     return MGX_OK;
+}
+
+// ---- test hook: LDS poisoning (mgx_test_set_lds_poison) ----
+// One workgroup claims all of a CU's LDS (160 KB), so no two of them share a CU; each stays ~10 us, far longer than the
+// dispatcher needs to hand out the grid, so a grid of 2 x CUs workgroups on an idle GPU visits every CU.  The pattern is a
+// NaN as fp64 and as two fp32 words.
+int g_poison_lds = 0;
+static constexpr int POISON_LDS_BYTES = 160 * 1024;
+__global__ void __launch_bounds__(1024) poison_lds_kernel(unsigned long long pattern) {
+    extern __shared__ unsigned long long poison_lds_[];
+    volatile unsigned long long* p = poison_lds_;
+    for (int i = threadIdx.x; i < POISON_LDS_BYTES / 8; i += 1024) p[i] = pattern;
+    __syncthreads();
+    const long long t0 = wall_clock64();  // 100 MHz
+    for (int k = 0; k < 4096 && wall_clock64() - t0 < 1000; k++) __builtin_amdgcn_s_sleep(16);
+}
+
+void poison_lds_launch(hipStream_t stream) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        (void)hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, POISON_LDS_BYTES);
+    }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(2 * cus), dim3(1024), POISON_LDS_BYTES, stream, 0x7FF4DEAD7FA0DEADull);
+}
+
+// counts, over every workgroup of the grid, the LDS words that carry `pattern` WITHOUT having written any: what the previous
+// launch left behind (mgx_test_lds_probe: the self-test of the poisoning)
+__global__ void __launch_bounds__(1024) probe_lds_kernel(unsigned long long pattern, unsigned long long* hits) {
+    extern __shared__ unsigned long long poison_lds_[];
+    volatile unsigned long long* p = poison_lds_;
+    unsigned n = 0;
+    for (int i = threadIdx.x; i < POISON_LDS_BYTES / 8; i += 1024) n += p[i] == pattern;
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(hits, (unsigned long long)n);
+    const long long t0 = wall_clock64();
+    for (int k = 0; k < 4096 && wall_clock64() - t0 < 1000; k++) __builtin_amdgcn_s_sleep(16);
 }
 
 int workspace(mgx_ctx* ctx, size_t bytes, void** out) {
@@ -203,6 +243,28 @@ int mgx_memset_zero(mgx_ctx* ctx, void* dst, size_t bytes) {
     MGX_REQUIRE(ctx && (bytes == 0 || dst), MGX_ERR_INVALID, "NULL argument");
     MGX_USE(ctx);
     return mgx::fill_zero(ctx, dst, bytes);
+}
+
+int mgx_test_set_lds_poison(int on) {
+    mgx::g_poison_lds = on != 0;
+    return MGX_OK;
+}
+
+int mgx_test_lds_probe(mgx_ctx* ctx, double* fraction) {
+    MGX_REQUIRE(ctx && fraction, MGX_ERR_INVALID, "NULL argument");
+    MGX_USE(ctx);
+    void* ws = nullptr;
+    MGX_TRY_RET(mgx::workspace(ctx, 8, &ws));
+    MGX_HIP(hipMemsetAsync(ws, 0, 8, ctx->compute));
+    MGX_HIP(hipFuncSetAttribute((const void*)mgx::probe_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mgx::POISON_LDS_BYTES));
+    const int blocks = ctx->num_cus;
+    MGX_LAUNCH(mgx::probe_lds_kernel, dim3(blocks), dim3(1024), mgx::POISON_LDS_BYTES, ctx->compute, 0x7FF4DEAD7FA0DEADull,
+               (unsigned long long*)ws);
+    unsigned long long hits = 0;
+    MGX_HIP(hipMemcpyAsync(&hits, ws, 8, hipMemcpyDeviceToHost, ctx->compute));
+    MGX_HIP(hipStreamSynchronize(ctx->compute));
+    *fraction = (double)hits / ((double)blocks * (mgx::POISON_LDS_BYTES / 8));
+    return MGX_OK;
 }
 
 int mgx_graph_begin(mgx_ctx* ctx) {

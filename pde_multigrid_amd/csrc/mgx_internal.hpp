@@ -55,6 +55,13 @@ struct mgx_ctx {
     int sweep_dbg = 0;     // diagnostic builds: 1 = cycle stamps, + 2 * ablation bits (sweep3d_xs_kernel)
     void* sweep_dev = nullptr;        // its device state: launch epoch, finished-workgroup counter, progress words
     unsigned* sweep_abort = nullptr;  // host-mapped word: != 0 once an inter-workgroup wait has given up
+    unsigned sync_spin_limit = 1u << 21;  // "sync.spin_limit": polls (each ~1 us) before such a wait gives up
+    unsigned handoff_fault = 0;           // "test.handoff_fault": test hook, see SweepSync::fault
+    int handoff_broken = 0;   // set when mgx_ctx_check has seen the abort word: the kernels whose workgroups wait for each other are not
+                              // used any more on this context (colour passes instead) until mgx_ctx_clear_abort(ctx, 1)
+    int gpu_exclusive = 1;    // "gpu.exclusive": 1 = this context has the GPU to itself (the assumption behind those kernels); 0 = the GPU
+                              // is shared with other contexts / processes: they are never launched
+    mutable int resident_occ = -1;  // workgroups of the resident Relax kernels per CU (occupancy API), -1 = not asked yet
     void* scratch = nullptr;  // small device workspace (reductions, tables)
     size_t scratch_bytes = 0;
     void* rccl_comm = nullptr;  // ncclComm_t
@@ -138,6 +145,18 @@ struct SmallDiv {
 // used from a thread other than its creator (ctypes, thread-ranks), whose current device is otherwise 0
 #define MGX_USE(ctx) MGX_HIP(hipSetDevice((ctx)->device))
 #define MGX_LAUNCH_CHECK() MGX_HIP(hipGetLastError())
+// every kernel launch of the library goes through here.  Test hook (mgx_test_set_lds_poison): when armed, each launch is preceded
+// by a launch that fills the LDS of every CU with signalling-NaN patterns, so that a kernel reading an LDS word before writing
+// it fails its parity test deterministically instead of depending on what the previous kernel happened to leave there.
+namespace mgx {
+extern int g_poison_lds;
+void poison_lds_launch(hipStream_t stream);
+}  // namespace mgx
+#define MGX_LAUNCH(kernel, grid, block, lds, stream, ...)                  \
+    do {                                                                   \
+        if (mgx::g_poison_lds) mgx::poison_lds_launch(stream);             \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); \
+    } while (0)
 #define MGX_TRY_RET(expr)            \
     do {                             \
         const int st_ = (expr);      \

@@ -680,14 +680,14 @@ int relax2d(mgx_ctx* ctx, real* v, const real* f, const int n[2], const real h[2
     MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "relax2d: ncycles = %d < 0", ncycles);
     const Lyap2<real> k = lyap<real>(h, a, A, alfa);
     if (ncycles > 0 && n[0] <= SMALL2_MAX && n[1] <= SMALL2_MAX) {
-        hipLaunchKernelGGL((relax2d_small_kernel<real>), dim3(1), dim3(1024), 0, ctx->compute, v, f, n[0], n[1], k, ncycles);
+        MGX_LAUNCH((relax2d_small_kernel<real>), dim3(1), dim3(1024), 0, ctx->compute, v, f, n[0], n[1], k, ncycles);
         MGX_LAUNCH_CHECK();
         return MGX_OK;
     }
     dim3 g(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), 1);
     for (int c = 0; c < ncycles; c++)
         for (int colour = 0; colour < 2; colour++)
-            hipLaunchKernelGGL((relax2d_colour_kernel<real>), g, blk2(), 0, ctx->compute, v, f, n[0], n[1], k, colour);
+            MGX_LAUNCH((relax2d_colour_kernel<real>), g, blk2(), 0, ctx->compute, v, f, n[0], n[1], k, colour);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -699,7 +699,7 @@ int residual2d(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[
     MGX_USE(ctx);
     int st = check_n2(n, "residual2d");
     if (st) return st;
-    hipLaunchKernelGGL((residual2d_kernel<real>), grd2(n[0], n[1]), blk2(), 0, ctx->compute, v, f, r, n[0], n[1],
+    MGX_LAUNCH((residual2d_kernel<real>), grd2(n[0], n[1]), blk2(), 0, ctx->compute, v, f, r, n[0], n[1],
                        lyap<real>(h, a, A, alfa));
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -713,7 +713,7 @@ int restrict2d(mgx_ctx* ctx, const real* fine, const int fn[2], real* coarse, co
     if (st) return st;
     st = check_coarse2(fn, cn, "restrict2d");
     if (st) return st;
-    hipLaunchKernelGGL((restrict2d_kernel<real>), grd2(cn[0], cn[1]), blk2(), 0, ctx->compute, fine, fn[0], coarse, cn[0],
+    MGX_LAUNCH((restrict2d_kernel<real>), grd2(cn[0], cn[1]), blk2(), 0, ctx->compute, fine, fn[0], coarse, cn[0],
                        cn[1]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -727,7 +727,7 @@ int interpolate2d(mgx_ctx* ctx, real* fine, const int fn[2], const real* coarse,
     if (st) return st;
     st = check_coarse2(fn, cn, "interpolate2d");
     if (st) return st;
-    hipLaunchKernelGGL((interpolate2d_kernel<real, ADD>), grd2(fn[0] - 2, fn[1] - 2), blk2(), 0, ctx->compute, fine, fn[0],
+    MGX_LAUNCH((interpolate2d_kernel<real, ADD>), grd2(fn[0] - 2, fn[1] - 2), blk2(), 0, ctx->compute, fine, fn[0],
                        fn[1], coarse, cn[0]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -742,7 +742,7 @@ int residual_restrict2d(mgx_ctx* ctx, const real* v, const real* f, const int n[
     if (st) return st;
     st = check_coarse2(n, cn, "residual_restrict2d");
     if (st) return st;
-    hipLaunchKernelGGL((residual_restrict2d_kernel<real>), grd2(cn[0], cn[1]), blk2(), 0, ctx->compute, v, f, n[0], n[1],
+    MGX_LAUNCH((residual_restrict2d_kernel<real>), grd2(cn[0], cn[1]), blk2(), 0, ctx->compute, v, f, n[0], n[1],
                        lyap<real>(h, a, A, alfa), coarse_f, cn[0], cn[1]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -756,7 +756,7 @@ int correct2d(mgx_ctx* ctx, real* fine, const int fn[2], const real* err, const 
     if (st) return st;
     for (int d = 0; d < 2; d++)  // N2/MultiGrid2D.cpp:351-352
         MGX_REQUIRE(fn[d] == en[d], MGX_ERR_SIZE, "apply_correction2d: size[%d] %d != %d", d, fn[d], en[d]);
-    hipLaunchKernelGGL((correct2d_kernel<real>), grd2(fn[0] - 2, fn[1] - 2), blk2(), 0, ctx->compute, fine, err, fn[0],
+    MGX_LAUNCH((correct2d_kernel<real>), grd2(fn[0] - 2, fn[1] - 2), blk2(), 0, ctx->compute, fine, err, fn[0],
                        fn[1]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -772,7 +772,7 @@ int set2d(mgx_ctx* ctx, real* g, const int n[2], real value, int modify_boundari
     if (modify_boundaries && value == (real)0 && !std::signbit(value)) {  // the cycle's "coarse v := 0" (:326)
         return fill_zero(ctx, g, (size_t)n[0] * n[1] * sizeof(real));
     }
-    hipLaunchKernelGGL((set2d_kernel<real>), grd2(n[0] - 2 * lo, n[1] - 2 * lo), blk2(), 0, ctx->compute, g, n[0], n[1],
+    MGX_LAUNCH((set2d_kernel<real>), grd2(n[0] - 2 * lo, n[1] - 2 * lo), blk2(), 0, ctx->compute, g, n[0], n[1],
                        value, lo);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -789,7 +789,7 @@ int jacobi2d(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[2], co
     const Lyap2<real> k = lyap<real>(h, a, A, alfa);
     real *src = v, *dst = tmp;
     for (int c = 0; c < ncycles; c++) {
-        hipLaunchKernelGGL((jacobi2d_kernel<real>), grd2(n[0], n[1]), blk2(), 0, ctx->compute, (const real*)src, dst, f, n[0], n[1],
+        MGX_LAUNCH((jacobi2d_kernel<real>), grd2(n[0], n[1]), blk2(), 0, ctx->compute, (const real*)src, dst, f, n[0], n[1],
                            k, omega);
         real* t = src; src = dst; dst = t;
     }
@@ -809,7 +809,7 @@ int mean_abs_error2d(mgx_ctx* ctx, const real* v, const int n[2], const real h[2
     if (st) return st;
     MGX_HIP(hipMemsetAsync(ws, 0, sizeof(double), ctx->compute));
     if (n[0] > 2 && n[1] > 2) {
-        hipLaunchKernelGGL((abs_error2d_kernel<real>), dim3(1, n[1] - 2), dim3(n[0] >= 256 ? 256 : 64), 0, ctx->compute, v, n[0],
+        MGX_LAUNCH((abs_error2d_kernel<real>), dim3(1, n[1] - 2), dim3(n[0] >= 256 ? 256 : 64), 0, ctx->compute, v, n[0],
                            n[1], h[0], h[1], a[0], a[1], (double*)ws);
         MGX_LAUNCH_CHECK();
     }
@@ -827,7 +827,7 @@ int init_v2d(mgx_ctx* ctx, real* v, const int n[2], const real h[2], const real 
     MGX_USE(ctx);
     int st = check_n2(n, "init_v2d");
     if (st) return st;
-    hipLaunchKernelGGL((init_v2d_kernel<real>), dim3(ceil_div(n[0], 64), ceil_div(n[1], 4)), dim3(64, 4, 1), 0, ctx->compute, v, n[0], n[1],
+    MGX_LAUNCH((init_v2d_kernel<real>), dim3(ceil_div(n[0], 64), ceil_div(n[1], 4)), dim3(64, 4, 1), 0, ctx->compute, v, n[0], n[1],
                        h[0], h[1], a[0], a[1]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -871,7 +871,7 @@ int cycle2d_down(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const
 #define MGX_CYC_DOWN(TT, NT, NP)                                                                                              \
     do {                                                                                                                      \
         MGX_TRY_RET(allow_lds(cycle2d_down_kernel<real, TT, NT, NP>, lds));                                                   \
-        hipLaunchKernelGGL((cycle2d_down_kernel<real, TT, NT, NP>), g, dim3(NT), lds, ctx->compute, vin, vout, f, n[0], n[1], k, \
+        MGX_LAUNCH((cycle2d_down_kernel<real, TT, NT, NP>), g, dim3(NT), lds, ctx->compute, vin, vout, f, n[0], n[1], k, \
                            npass, v_zero, coarse_f, cx, cy);                                                                  \
     } while (0)
     if (T == 64) MGX_CYC_DOWN(64, 1024, 3);        // 38 x 75 = 2850 points of a colour / 1024 threads
@@ -900,7 +900,7 @@ int cycle2d_up(mgx_ctx* ctx, const real* vin, real* vout, const real* f, const i
 #define MGX_CYC_UP(TT, NT, NP)                                                                                              \
     do {                                                                                                                    \
         MGX_TRY_RET(allow_lds(cycle2d_up_kernel<real, TT, NT, NP>, lds));                                                   \
-        hipLaunchKernelGGL((cycle2d_up_kernel<real, TT, NT, NP>), g, dim3(NT), lds, ctx->compute, vin, vout, f, n[0], n[1], k, \
+        MGX_LAUNCH((cycle2d_up_kernel<real, TT, NT, NP>), g, dim3(NT), lds, ctx->compute, vin, vout, f, n[0], n[1], k, \
                            npass, coarse_v, cn[0], cn[1]);                                                                  \
     } while (0)
     if (T == 64) MGX_CYC_UP(64, 1024, 3);
@@ -948,7 +948,7 @@ int cycle2d_tail(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const i
     const real h0[2] = {h[0], h[1]};
     const Lyap2<real> k = lyap<real>(h0, a, A, alfa);
     MGX_TRY_RET(allow_lds(cycle2d_tail_kernel<real>, lds));
-    hipLaunchKernelGGL((cycle2d_tail_kernel<real>), dim3(1), dim3(1024), lds, ctx->compute, L, k, v1, v2, top_zero);
+    MGX_LAUNCH((cycle2d_tail_kernel<real>), dim3(1), dim3(1024), lds, ctx->compute, L, k, v1, v2, top_zero);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }

@@ -2153,7 +2153,7 @@ static int relax3d_natural(mgx_ctx* ctx, real* v, const real* f, const int n[3],
     dim3 g(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2);
     for (int k = 0; k < ncycles; k++)
         for (int colour = 0; colour < 2; colour++)
-            hipLaunchKernelGGL((relax3d_colour_kernel<real>), g, blk(), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2,
+            MGX_LAUNCH((relax3d_colour_kernel<real>), g, blk(), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2,
                                hz2, colour);
     return MGX_OK;
 }
@@ -2168,7 +2168,7 @@ static void launch_xs(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int 
     if (TYW == 4 && R == 4 && ctx->relax_ablate) {  // diagnostics only
 #define MGX_ABL(A)                                                                                                   \
     case A:                                                                                                          \
-        hipLaunchKernelGGL((relax3d_xs_kernel<real, 4, 4, A>), dim3(nblocks), dim3(64, 4, 1), 0, ctx->compute,          \
+        MGX_LAUNCH((relax3d_xs_kernel<real, 4, 4, A>), dim3(nblocks), dim3(64, 4, 1), 0, ctx->compute,          \
                            (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd); \
         return;
         switch (ctx->relax_ablate) {
@@ -2179,7 +2179,7 @@ static void launch_xs(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int 
     }
 #endif
     note_relax_kernel<real>(ctx, "relax3d_xs_kernel", TYW, R, 0);
-    hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
+    MGX_LAUNCH((relax3d_xs_kernel<real, TYW, R>), dim3(nblocks), dim3(64, TYW, 1), 0, ctx->compute,
                        (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, ctx->relax_xcd);
 }
 
@@ -2205,15 +2205,15 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
     const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
     note_relax_kernel<real>(ctx, kind ? "relax3d_xs_pipe_kernel" : "relax3d_xs_lds_kernel", WX, WY, R, kind == 2 && R == 2 && WX * WY == 16);
     if (kind == 2 && R == 2 && WX * WY == 16)  // f is read once per pass: non-temporal loads
-        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, WX, WY, (R == 2 && WX * WY == 16 ? R : 2), true>), grid, block, 0,
+        MGX_LAUNCH((relax3d_xs_pipe_kernel<real, WX, WY, (R == 2 && WX * WY == 16 ? R : 2), true>), grid, block, 0,
                            ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, xcd);
 #ifdef MGX_DIAGNOSTICS
     else if (kind == 0)
-        hipLaunchKernelGGL((relax3d_xs_lds_kernel<real, WX, WY, R>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy,
+        MGX_LAUNCH((relax3d_xs_lds_kernel<real, WX, WY, R>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy,
                            zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, xcd);
 #endif
     else
-        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, WX, WY, R>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy,
+        MGX_LAUNCH((relax3d_xs_pipe_kernel<real, WX, WY, R>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy,
                            zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, xcd);
 }
 
@@ -2253,10 +2253,10 @@ static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, in
         const dim3 grid2((unsigned)gx2 * gy2 * gz2);
         note_relax_kernel<real>(ctx, "relax3d_xs_pipe_v2_kernel", 2, 8, 2, fnt);
         if (fnt)
-            hipLaunchKernelGGL((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, true>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy,
+            MGX_LAUNCH((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, true>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy,
                                zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx2, gy2, xcd);
         else
-            hipLaunchKernelGGL((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, false>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy,
+            MGX_LAUNCH((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, false>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy,
                                zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx2, gy2, xcd);
         return true;
     }
@@ -2325,7 +2325,7 @@ static bool relax3d_xs_first_sweep_zero(mgx_ctx* ctx, real* v, const real* f, in
     snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,2,%d,2,%s,3>", sizeof(real) == 8 ? "double" : "float",
              low ? 4 : 8, fnt ? "true" : "false");
 #define MGX_Z1(WYY, F)                                                                                                           \
-    hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, WYY, 2, F, 3>), grid, dim3(64, 2 * WYY, 1), 0, ctx->compute, f, v, f, sx, sy, zbeg, zend, \
+    MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, WYY, 2, F, 3>), grid, dim3(64, 2 * WYY, 1), 0, ctx->compute, f, v, f, sx, sy, zbeg, zend, \
                        hx2, hy2, hz2, 1, zchunk, gx, gy, xcd, (const real*)nullptr, 0, 0, sz, 0)
     if (low) MGX_Z1(4, false);
     else if (fnt) MGX_Z1(8, true);
@@ -2375,7 +2375,7 @@ static bool relax3d_xs_pass2(mgx_ctx* ctx, real* v, const real* f, int sx, int s
     const int M = (sx + 1) / 2;
     const int gx = ceil_div(M - 1, 64), gy = ceil_div(sy - 2, TYW * R), gz1 = ze1 - zb1, gz2 = ze2 - zb2;
     note_relax_kernel<real>(ctx, "relax3d_xs_kernel", TYW, R, 0);
-    hipLaunchKernelGGL((relax3d_xs_kernel<real, TYW, R>), dim3((unsigned)gx * gy * (gz1 + gz2)), dim3(64, TYW, 1), 0, ctx->compute, (const real*)v, v, f,
+    MGX_LAUNCH((relax3d_xs_kernel<real, TYW, R>), dim3((unsigned)gx * gy * (gz1 + gz2)), dim3(64, TYW, 1), 0, ctx->compute, (const real*)v, v, f,
                        sx, sy, zb1, ze1, hx2, hy2, hz2, colour, zchunk, gx, gy, 0, gz1, zb2, ze2);
     return true;
 }
@@ -2417,7 +2417,7 @@ int relax3d(mgx_ctx* ctx, real* v, const real* f, const int n[3], const real h[3
     MGX_REQUIRE(ncycles >= 0, MGX_ERR_INVALID, "relax3d: ncycles = %d < 0", ncycles);
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];  // N3/MultiGrid3D.cpp:498-500
     if (ncycles > 0 && n[0] <= SMALL_MAX && n[1] <= SMALL_MAX && n[2] <= SMALL_MAX && ctx->relax_small) {
-        hipLaunchKernelGGL((relax3d_small_kernel<real, L>), dim3(1), dim3(1024), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2,
+        MGX_LAUNCH((relax3d_small_kernel<real, L>), dim3(1), dim3(1024), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2,
                            hz2, ncycles);
         MGX_LAUNCH_CHECK();
         return MGX_OK;
@@ -2457,12 +2457,12 @@ int relax3d_from_zero(mgx_ctx* ctx, real* v, const real* f, const int n[3], cons
     int s0 = 1;
     if (L::xsplit && relax3d_xs_first_sweep_zero<real>(ctx, v, f, n[0], n[1], n[2], hx2, hy2, hz2)) s0 = 2;  // red and black in one launch
     else
-        hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, L>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
+        MGX_LAUNCH((relax3d_zero_colour_kernel<real, L>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
                            ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0, 1);
     for (int s = s0; s < 2 * ncycles; s++) {
         if (L::xsplit) relax3d_xs_pass<real>(ctx, v, f, n[0], n[1], 1, n[2] - 1, hx2, hy2, hz2, s & 1);
         else
-            hipLaunchKernelGGL((relax3d_colour_kernel<real>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
+            MGX_LAUNCH((relax3d_colour_kernel<real>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2), blk(), 0,
                                ctx->compute, v, f, n[0], n[1], n[2], hx2, hy2, hz2, s & 1);
     }
     MGX_LAUNCH_CHECK();
@@ -2484,7 +2484,7 @@ int residual3d(mgx_ctx* ctx, const real* v, const real* f, real* r, const int n[
         hz2 = (real)1 / hz2;
     }
 #define MGX_RES(M) \
-    hipLaunchKernelGGL((residual3d_kernel<real, L, M>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, v, f, r, n[0], n[1], n[2], hx2, hy2, hz2)
+    MGX_LAUNCH((residual3d_kernel<real, L, M>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, v, f, r, n[0], n[1], n[2], hx2, hy2, hz2)
     if (mode == MGX_RESIDUAL_REF_COMPAT) {
         if (rcp) MGX_RES(2); else MGX_RES(0);
     } else {
@@ -2503,7 +2503,7 @@ int restrict3d(mgx_ctx* ctx, const real* fine, const int fn[3], real* coarse, co
     if (st) return st;
     st = check_coarse3(fn, cn, "restrict3d");
     if (st) return st;
-    hipLaunchKernelGGL((restrict3d_kernel<real, L>), grd(cn[0], cn[1], cn[2]), blk(), 0, ctx->compute, fine, fn[0], fn[1],
+    MGX_LAUNCH((restrict3d_kernel<real, L>), grd(cn[0], cn[1], cn[2]), blk(), 0, ctx->compute, fine, fn[0], fn[1],
                        coarse, cn[0], cn[1], cn[2], 0, 0, 0);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2522,7 +2522,7 @@ int restrict3d_slab(mgx_ctx* ctx, const real* fine, const int fn[3], int fzoff, 
     MGX_REQUIRE(pzbeg >= 0 && pzend <= cn[2] && pzbeg <= pzend && fzoff >= 0 && czoff >= 0 && czoff <= pzbeg, MGX_ERR_INVALID,
                 "restrict_slab: bad plane range");
     if (pzbeg == pzend) return MGX_OK;
-    hipLaunchKernelGGL((restrict3d_kernel<real, XSplit>), grd(cn[0], cn[1], pzend - pzbeg), blk(), 0, ctx->compute, fine, fn[0],
+    MGX_LAUNCH((restrict3d_kernel<real, XSplit>), grd(cn[0], cn[1], pzend - pzbeg), blk(), 0, ctx->compute, fine, fn[0],
                        fn[1], coarse, cn[0], cn[1], cn[2], fzoff, czoff, pzbeg);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2537,10 +2537,10 @@ int interpolate3d(mgx_ctx* ctx, real* fine, const int fn[3], const real* coarse,
     st = check_coarse3(fn, cn, "interpolate3d");
     if (st) return st;
     if (L::xsplit)
-        hipLaunchKernelGGL((interpolate3d_xs_kernel<real, ADD>), grd((fn[0] + 1) / 2 - 1, cn[1] - 1, cn[2] - 1), blk(), 0,
+        MGX_LAUNCH((interpolate3d_xs_kernel<real, ADD>), grd((fn[0] + 1) / 2 - 1, cn[1] - 1, cn[2] - 1), blk(), 0,
                            ctx->compute, fine, fn[0], fn[1], 0, coarse, cn[0], cn[1], 0, 0);
     else
-        hipLaunchKernelGGL((interpolate3d_kernel<real, L, ADD>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute,
+        MGX_LAUNCH((interpolate3d_kernel<real, L, ADD>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute,
                            fine, fn[0], fn[1], fn[2], coarse, cn[0], cn[1]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2554,7 +2554,7 @@ int correct3d(mgx_ctx* ctx, real* fine, const int fn[3], const real* err, const 
     if (st) return st;
     for (int d = 0; d < 3; d++)  // N3/MultiGrid3D.cpp:660-662
         MGX_REQUIRE(fn[d] == en[d], MGX_ERR_SIZE, "apply_correction3d: size[%d] %d != %d", d, fn[d], en[d]);
-    hipLaunchKernelGGL((correct3d_kernel<real, L>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute, fine, err,
+    MGX_LAUNCH((correct3d_kernel<real, L>), grd(fn[0] - 2, fn[1] - 2, fn[2] - 2), blk(), 0, ctx->compute, fine, err,
                        fn[0], fn[1], fn[2]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2573,7 +2573,7 @@ int set3d(mgx_ctx* ctx, real* g, const int n[3], real value, int modify_boundari
         const size_t elems = Geo<L, real>(n[0], n[1]).PL * (size_t)n[2];  // natural layout: PL = n[0] * n[1]
         return fill_zero(ctx, g, elems * sizeof(real));
     }
-    hipLaunchKernelGGL((set3d_kernel<real, L>), grd(n[0] - 2 * lo, n[1] - 2 * lo, n[2] - 2 * lo), blk(), 0, ctx->compute, g,
+    MGX_LAUNCH((set3d_kernel<real, L>), grd(n[0] - 2 * lo, n[1] - 2 * lo, n[2] - 2 * lo), blk(), 0, ctx->compute, g,
                        n[0], n[1], n[2], value, lo);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2588,7 +2588,7 @@ int set3d_slab(mgx_ctx* ctx, real* g, int sx, int sy, int zbeg, int zend, real v
     if (zend == zbeg) return MGX_OK;
     // set3d_kernel with lo = 1 writes the planes 1 .. sz-2 of the array it is given: hand it the planes zbeg-1 .. zend
     const Geo<XSplit, real> ge(sx, sy);
-    hipLaunchKernelGGL((set3d_kernel<real, XSplit>), grd(sx - 2, sy - 2, zend - zbeg), blk(), 0, ctx->compute,
+    MGX_LAUNCH((set3d_kernel<real, XSplit>), grd(sx - 2, sy - 2, zend - zbeg), blk(), 0, ctx->compute,
                        g + ge.PL * (size_t)zbeg - ge.PL, sx, sy, zend - zbeg + 2, value, 1);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2648,7 +2648,7 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
         }
         dim3 g(gx * gy * ceil_div(pzend - pzbeg, pzc), 1, 1);
 #define MGX_RRP(M, W, OW)                                                                                                \
-    hipLaunchKernelGGL((residual_restrict3d_xs_pipe_kernel<real, M, W, OW>), g, dim3(64, W, 1), 0, ctx->compute, v, f,    \
+    MGX_LAUNCH((residual_restrict3d_xs_pipe_kernel<real, M, W, OW>), g, dim3(64, W, 1), 0, ctx->compute, v, f,    \
                        n[0], n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzc, fzoff, czoff, pzbeg, pzend,   \
                        gx, gy, ctx->rr_xcd >= 1)
 #define MGX_RRP_W(M)                                                                                                     \
@@ -2672,7 +2672,7 @@ static int residual_restrict3d_xs_launch(mgx_ctx* ctx, const real* v, const real
     while (pzchunk > 1 && (long long)gx * gy * ceil_div(pzend - pzbeg, pzchunk) < 4LL * ctx->num_cus) pzchunk >>= 1;
     dim3 g(gx * gy * ceil_div(pzend - pzbeg, pzchunk), 1, 1);
 #define MGX_RR(M, C, W)                                                                                                  \
-    hipLaunchKernelGGL((residual_restrict3d_xs_kernel<real, M, C, W>), g, dim3(64, W, 1), 0, ctx->compute, v, f, n[0], n[1], \
+    MGX_LAUNCH((residual_restrict3d_xs_kernel<real, M, C, W>), g, dim3(64, W, 1), 0, ctx->compute, v, f, n[0], n[1], \
                        n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend, gx, gy,      \
                        ctx->rr_xcd >= 2)
 #define MGX_RR_W(M, C)                             \
@@ -2717,10 +2717,10 @@ int residual_restrict3d(mgx_ctx* ctx, const real* v, const real* f, const int n[
     while (pzchunk > 1 && (long long)tiles * ceil_div(cn[2], pzchunk) < 4LL * ctx->num_cus) pzchunk >>= 1;
     dim3 g(ceil_div(cn[0], CTX), ceil_div(cn[1], CTY), ceil_div(cn[2], pzchunk));
     if (mode == MGX_RESIDUAL_REF_COMPAT)
-        hipLaunchKernelGGL((residual_restrict3d_kernel<real, L, 0, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1],
+        MGX_LAUNCH((residual_restrict3d_kernel<real, L, 0, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1],
                            n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, 0, 0, 0, cn[2]);
     else
-        hipLaunchKernelGGL((residual_restrict3d_kernel<real, L, 1, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1],
+        MGX_LAUNCH((residual_restrict3d_kernel<real, L, 1, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0], n[1],
                            n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, 0, 0, 0, cn[2]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2787,7 +2787,7 @@ int smooth_residual_restrict3d_xs(mgx_ctx* ctx, real* v, const real* f, const in
             if (2 * ncycles - 1 >= 2 && relax3d_xs_first_sweep_zero<real>(ctx, v, f, n[0], n[1], n[2], hx2, hy2, hz2)) {
                 s = 2;  // the whole first sweep in one launch
             } else {
-                hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, XSplit>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2),
+                MGX_LAUNCH((relax3d_zero_colour_kernel<real, XSplit>), dim3(ceil_div((n[0] + 1) / 2, 64), ceil_div(n[1] - 2, 4), n[2] - 2),
                                    blk(), 0, ctx->compute, v, f, n[0], n[1], hx2, hy2, hz2, 0, 1);
                 s = 1;
             }
@@ -2818,7 +2818,7 @@ int init_f3d(mgx_ctx* ctx, real* f, const int n[3], double c, const double* tx, 
     MGX_HIP(hipMemcpyAsync(d, tx, n[0] * sizeof(double), hipMemcpyHostToDevice, ctx->compute));
     MGX_HIP(hipMemcpyAsync(d + n[0], ty, n[1] * sizeof(double), hipMemcpyHostToDevice, ctx->compute));
     MGX_HIP(hipMemcpyAsync(d + n[0] + n[1], tz, n[2] * sizeof(double), hipMemcpyHostToDevice, ctx->compute));
-    hipLaunchKernelGGL((init_f3d_kernel<real, L>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, f, n[0], n[1], n[2], c, d,
+    MGX_LAUNCH((init_f3d_kernel<real, L>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, f, n[0], n[1], n[2], c, d,
                        d + n[0], d + n[0] + n[1]);
     MGX_LAUNCH_CHECK();
     MGX_HIP(hipStreamSynchronize(ctx->compute));  // host tables may be freed by the caller
@@ -2832,7 +2832,7 @@ int relayout3d(mgx_ctx* ctx, const real* src, real* dst, const int n[3]) {
     MGX_REQUIRE(src != dst, MGX_ERR_INVALID, "relayout3d: in-place conversion is not supported");
     int st = check_n3(n, "relayout3d");
     if (st) return st;
-    hipLaunchKernelGGL((relayout3d_kernel<real, LS, LD>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, src, dst, n[0], n[1]);
+    MGX_LAUNCH((relayout3d_kernel<real, LS, LD>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, src, dst, n[0], n[1]);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -2884,7 +2884,7 @@ int relax3d_zero_colour_slab(mgx_ctx* ctx, real* v, const real* f, int sx, int s
                 "relax_zero_colour_slab: bad colour / plane range");
     if (zend == zbeg) return MGX_OK;
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
-    hipLaunchKernelGGL((relax3d_zero_colour_kernel<real, XSplit>), dim3(ceil_div((sx + 1) / 2, 64), ceil_div(sy - 2, 4), zend - zbeg), blk(), 0,
+    MGX_LAUNCH((relax3d_zero_colour_kernel<real, XSplit>), dim3(ceil_div((sx + 1) / 2, 64), ceil_div(sy - 2, 4), zend - zbeg), blk(), 0,
                        ctx->compute, v, f, sx, sy, hx2, hy2, hz2, (colour + zoff) & 1, zbeg);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2916,10 +2916,10 @@ int residual_restrict3d_slab(mgx_ctx* ctx, const real* v, const real* f, const i
     while (pzchunk > 1 && (long long)tiles * ceil_div(pzend - pzbeg, pzchunk) < 4LL * ctx->num_cus) pzchunk >>= 1;
     dim3 g(ceil_div(cn[0], CTX), ceil_div(cn[1], CTY), ceil_div(pzend - pzbeg, pzchunk));
     if (mode == MGX_RESIDUAL_REF_COMPAT)
-        hipLaunchKernelGGL((residual_restrict3d_kernel<real, XSplit, 0, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0],
+        MGX_LAUNCH((residual_restrict3d_kernel<real, XSplit, 0, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0],
                            n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend);
     else
-        hipLaunchKernelGGL((residual_restrict3d_kernel<real, XSplit, 1, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0],
+        MGX_LAUNCH((residual_restrict3d_kernel<real, XSplit, 1, CTX, CTY>), g, blk(), 0, ctx->compute, v, f, n[0],
                            n[1], n[2], hx2, hy2, hz2, coarse_f, cn[0], cn[1], cn[2], pzchunk, fzoff, czoff, pzbeg, pzend);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -2951,7 +2951,7 @@ int residual_sumsq3d_slab(mgx_ctx* ctx, const real* v, const real* f, int sx, in
     MGX_TRY_RET(workspace(ctx, rows * sizeof(double), &ws));
     const dim3 g(sy - 2, zend - zbeg);
 #define MGX_RES(M)                                                                                                            \
-    hipLaunchKernelGGL((residual_sumsq3d_kernel<real, XSplit, M>), g, dim3(256), 0, ctx->compute, v, f, sx, sy, zbeg, hx2, hy2, \
+    MGX_LAUNCH((residual_sumsq3d_kernel<real, XSplit, M>), g, dim3(256), 0, ctx->compute, v, f, sx, sy, zbeg, hx2, hy2, \
                        hz2, (double*)ws)
     if (mode == MGX_RESIDUAL_REF_COMPAT) {
         if (rcp) MGX_RES(2); else MGX_RES(0);
@@ -2959,7 +2959,7 @@ int residual_sumsq3d_slab(mgx_ctx* ctx, const real* v, const real* f, int sx, in
         if (rcp) MGX_RES(3); else MGX_RES(1);
     }
 #undef MGX_RES
-    hipLaunchKernelGGL(residual_sumsq_final_kernel, dim3(1), dim3(1024), 0, ctx->compute, (const double*)ws, rows, dev_out);
+    MGX_LAUNCH(residual_sumsq_final_kernel, dim3(1), dim3(1024), 0, ctx->compute, (const double*)ws, rows, dev_out);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -2979,19 +2979,19 @@ int interpolate_correct3d_slab(mgx_ctx* ctx, real* v, const int n[3], int fzoff,
     if (pzbeg == pzend) return MGX_OK;
     const dim3 g = grd((n[0] + 1) / 2 - 1, cn[1] - 1, pzend - pzbeg);
     if (!add) {  // plain Interpolate (FMG, N3/MultiGrid3D.cpp:577): all interior points of the fine planes
-        hipLaunchKernelGGL((interpolate3d_xs_kernel<real, false, -1>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
+        MGX_LAUNCH((interpolate3d_xs_kernel<real, false, -1>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
                            cn[0], cn[1], czoff, pzbeg);
         MGX_LAUNCH_CHECK();
         return MGX_OK;
     }
     if (colour < 0)
-        hipLaunchKernelGGL((interpolate3d_xs_kernel<real, true, -1>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
+        MGX_LAUNCH((interpolate3d_xs_kernel<real, true, -1>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
                            cn[0], cn[1], czoff, pzbeg);
     else if (colour == 0)
-        hipLaunchKernelGGL((interpolate3d_xs_kernel<real, true, 0>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
+        MGX_LAUNCH((interpolate3d_xs_kernel<real, true, 0>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
                            cn[0], cn[1], czoff, pzbeg);
     else
-        hipLaunchKernelGGL((interpolate3d_xs_kernel<real, true, 1>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
+        MGX_LAUNCH((interpolate3d_xs_kernel<real, true, 1>), g, blk(), 0, ctx->compute, v, n[0], n[1], fzoff, coarse_v,
                            cn[0], cn[1], czoff, pzbeg);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
@@ -3024,7 +3024,7 @@ static void corr_pset_launch(mgx_ctx* ctx, real* v, int sx, int sy, int fzoff, c
     if (pzend <= pzbeg) return;
     const int nk = (cn[1] - 2) / PH + 1;
     if (PW != 256) return;  // relax3d_xs_pipe_kernel<.., 2> corrects everything it reads itself: its set P is empty
-    hipLaunchKernelGGL((correct_pset3d_xs_kernel<real>), dim3(ceil_div(M - 1, 64), ceil_div(nk, 4), pzend - pzbeg), blk(), 0, ctx->compute, v,
+    MGX_LAUNCH((correct_pset3d_xs_kernel<real>), dim3(ceil_div(M - 1, 64), ceil_div(nk, 4), pzend - pzbeg), blk(), 0, ctx->compute, v,
                        sx, sy, coarse_v, cn[0], cn[1], PW, PH, 0, fzoff, czoff, pzbeg, zmin, zmax);
     // no column part any more: both correcting kernels correct the values they take from the neighbouring tile themselves
     (void)M;
@@ -3051,10 +3051,10 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
         memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
         const dim3 grid2((unsigned)gx2 * gy2 * gz2);
         if (fnt2)
-            hipLaunchKernelGGL((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, true, 2>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx,
+            MGX_LAUNCH((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, true, 2>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx,
                                sy, zb, ze, hx2, hy2, hz2, colour, zchunk, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
         else
-            hipLaunchKernelGGL((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, false, 2>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx,
+            MGX_LAUNCH((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, false, 2>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx,
                                sy, zb, ze, hx2, hy2, hz2, colour, zchunk, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
         return;
     }
@@ -3071,10 +3071,10 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
         memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
         const dim3 gridl((unsigned)gxl * gyl * gzl);
         if (fntl)
-            hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 4, 2, true, 2>), gridl, dim3(64, 8, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zb,
+            MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, 4, 2, true, 2>), gridl, dim3(64, 8, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zb,
                                ze, hx2, hy2, hz2, colour, zchunk, gxl, gyl, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
         else
-            hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 4, 2, false, 2>), gridl, dim3(64, 8, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zb,
+            MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, 4, 2, false, 2>), gridl, dim3(64, 8, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zb,
                                ze, hx2, hy2, hz2, colour, zchunk, gxl, gyl, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
         return;
     }
@@ -3092,10 +3092,10 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
              fnt ? "true" : "false");
     memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
     if (fnt)
-        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 8, 2, true, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
+        MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, 8, 2, true, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
                            hx2, hy2, hz2, colour, zchunk, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax);
     else
-        hipLaunchKernelGGL((relax3d_xs_pipe_kernel<real, 2, 8, 2, false, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
+        MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, 8, 2, false, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
                            hx2, hy2, hz2, colour, zchunk, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax);
 }
 
@@ -3186,7 +3186,7 @@ int jacobi3d(mgx_ctx* ctx, real* v, real* tmp, const real* f, const int n[3], co
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
     real *src = v, *dst = tmp;
     for (int k = 0; k < ncycles; k++) {
-        hipLaunchKernelGGL((jacobi3d_kernel<real, L>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, (const real*)src, dst, f,
+        MGX_LAUNCH((jacobi3d_kernel<real, L>), grd(n[0], n[1], n[2]), blk(), 0, ctx->compute, (const real*)src, dst, f,
                            n[0], n[1], n[2], hx2, hy2, hz2, omega);
         real* t = src; src = dst; dst = t;
     }
@@ -3214,7 +3214,7 @@ int diff_stats3d(mgx_ctx* ctx, const real* v, const int n[3], const double* tx, 
     MGX_HIP(hipMemcpyAsync(d + 4, tx, n[0] * sizeof(double), hipMemcpyHostToDevice, ctx->compute));
     MGX_HIP(hipMemcpyAsync(d + 4 + n[0], ty, n[1] * sizeof(double), hipMemcpyHostToDevice, ctx->compute));
     MGX_HIP(hipMemcpyAsync(d + 4 + n[0] + n[1], tz, n[2] * sizeof(double), hipMemcpyHostToDevice, ctx->compute));
-    hipLaunchKernelGGL((diff_stats3d_kernel<real, L>), dim3(1, n[1], n[2]), dim3(n[0] >= 256 ? 256 : 64), 0, ctx->compute, v, n[0],
+    MGX_LAUNCH((diff_stats3d_kernel<real, L>), dim3(1, n[1], n[2]), dim3(n[0] >= 256 ? 256 : 64), 0, ctx->compute, v, n[0],
                        n[1], n[2], d + 4, d + 4 + n[0], d + 4 + n[0] + n[1], d);
     MGX_LAUNCH_CHECK();
     MGX_HIP(hipMemcpyAsync(host_out, d, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->compute));
@@ -3267,7 +3267,7 @@ int cycle3d_tail(mgx_ctx* ctx, int nlev, real* const* v, real* const* f, const i
     bool rcp = ctx->rr_rcp != 0;
     for (int l = 0; l < nlev && rcp; l++)
         rcp = exact_reciprocal(T.hx[l] * T.hx[l]) && exact_reciprocal(T.hy[l] * T.hy[l]) && exact_reciprocal(T.hz[l] * T.hz[l]);
-    hipLaunchKernelGGL((cycle3d_tail_kernel<real, L>), dim3(1), dim3(1024), lds, ctx->compute, T, v1, v2, mode | (rcp ? 2 : 0), top_zero);
+    MGX_LAUNCH((cycle3d_tail_kernel<real, L>), dim3(1), dim3(1024), lds, ctx->compute, T, v1, v2, mode | (rcp ? 2 : 0), top_zero);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }
@@ -3284,7 +3284,7 @@ int norm2(mgx_ctx* ctx, const real* x, size_t count, double* host_sumsq) {
         size_t blocks = (count + 255) / 256;
         const size_t cap = (size_t)ctx->num_cus * 8;
         if (blocks > cap) blocks = cap;
-        hipLaunchKernelGGL((sumsq_kernel<real>), dim3((unsigned)blocks), dim3(256), 0, ctx->compute, x, count, (double*)ws);
+        MGX_LAUNCH((sumsq_kernel<real>), dim3((unsigned)blocks), dim3(256), 0, ctx->compute, x, count, (double*)ws);
         MGX_LAUNCH_CHECK();
     }
     MGX_HIP(hipMemcpyAsync(host_sumsq, ws, sizeof(double), hipMemcpyDeviceToHost, ctx->compute));
@@ -3557,6 +3557,15 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "relax3d.resident")) {
         MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "set_param: relax3d.resident = %d not in {0, 1, 2}", value);
         ctx->relax_resident = value;
+    } else if (!strcmp(name, "sync.spin_limit")) {
+        MGX_REQUIRE(value >= 1, MGX_ERR_INVALID, "set_param: sync.spin_limit = %d < 1", value);
+        ctx->sync_spin_limit = (unsigned)value;  // polls before a wait between workgroups gives up (mgx_sync.hpp)
+    } else if (!strcmp(name, "test.handoff_fault")) {
+        MGX_REQUIRE(value >= 0 && value < (1 << 20), MGX_ERR_INVALID, "set_param: test.handoff_fault = %d out of range", value);
+        ctx->handoff_fault = (unsigned)value;  // TEST HOOK: != 0 makes workgroup 0 of those kernels wait for tags nobody writes
+    } else if (!strcmp(name, "gpu.exclusive")) {
+        MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: gpu.exclusive = %d not in {0, 1}", value);
+        ctx->gpu_exclusive = value;  // 0: the GPU is shared -> no kernel whose workgroups wait for each other is launched
     } else if (!strcmp(name, "relax3d.corr_low")) {
         MGX_REQUIRE(value == 0 || value == 1, MGX_ERR_INVALID, "set_param: relax3d.corr_low = %d not in {0, 1}", value);
         ctx->corr_low = value;  // the correcting red pass in 8-wave workgroups, two to a CU (fp64)
@@ -3584,7 +3593,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "relax3d.fused_ilv")) {
         ctx->sweep_ilv = value ? 1 : 0;  // sweep3d_xs_kernel: memory instructions in groups between the rows of the arithmetic (1) or all first (0)
     } else if (!strcmp(name, "relax3d.fused_mid")) {
-        ctx->sweep_mid = value ? 1 : 0;  // cache-resident levels (33 ... 129 points per row): one launch per sweep (sweep3d_xs_mid_kernel)
+        MGX_REQUIRE(value >= 0 && value <= 2, MGX_ERR_INVALID, "set_param: relax3d.fused_mid = %d not in {0, 1, 2}", value);
+        ctx->sweep_mid = value;  // 2: rows of 129 points too (slower there than two passes; tests).  cache-resident levels (33 ... 129 points per row): one launch per sweep (sweep3d_xs_mid_kernel)
     } else if (!strcmp(name, "relax3d.fused_dbg")) {
 #ifdef MGX_DIAGNOSTICS
         ctx->sweep_dbg = value;  // 1 = cycle stamps, + 2 * ablation bits: WRONG results

@@ -340,7 +340,7 @@ bool relax_rr3d_xs_launch(mgx_ctx* ctx, real* v, const real* f, const int n[3], 
         qz = (real)1 / hz2;
     }
 #define MGX_BRR_D(M, W, D)                                                                                                     \
-    hipLaunchKernelGGL((relax_rr3d_xs_kernel<real, M, W, D>), g, dim3(64, W, 1), 0, ctx->compute, (const real*)v, v, f, n[0], n[1], \
+    MGX_LAUNCH((relax_rr3d_xs_kernel<real, M, W, D>), g, dim3(64, W, 1), 0, ctx->compute, (const real*)v, v, f, n[0], n[1], \
                        n[2], hx2, hy2, hz2, qx, qy, qz, coarse_f, cn[0], cn[1], cn[2], pzc, gx, gy, ctx->rr_xcd >= 1, pzbeg, pzend, fzoff,   \
                        czoff, ctx->rr_black_abl)
 #ifdef MGX_DIAGNOSTICS

@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(1024)
     const int y0 = 1 + ty * RT, z0 = 1 + tz * RT;
     const bool has_ym = ty > 0, has_yp = ty < gy - 1, has_zm = tz > 0, has_zp = tz < gz - 1;
     const u64 ep = *sync.epoch;  // written by the previous launch's last workgroup: a kernel boundary lies in between
+    const u64 ep_wait = ep + (blockIdx.x == 0 ? sync.fault : 0u);  // the epoch of the tags this workgroup waits for (test hook: see SweepSync)
     const double rd = relax3d_rd<real>(hx2, hy2, hz2);
     const unsigned facesz = RT * 64, tilesz = 4 * facesz, bufsz = gridDim.x * tilesz;  // xbuf[2][tile][face][RT][64] elements
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, (int)xbytes, 0x00020000);
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(1024)
             if (have) {
                 const int nb = face == 0 ? (int)blockIdx.x - 1 : (face == 1 ? (int)blockIdx.x + 1 : (face == 2 ? (int)blockIdx.x - gy : (int)blockIdx.x + gy));
                 const unsigned src = (unsigned)((p - 1) & 1) * bufsz + (unsigned)nb * tilesz + (unsigned)(face ^ 1) * facesz;
-                const u64 tag = pass_tag<real>(ep, p - 1);
+                const u64 tag = pass_tag<real>(ep_wait, p - 1);
 #pragma unroll
                 for (int k2 = 0; k2 < 2; k2++) {
                     const int k = 2 * (w & 3) + k2;
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(1024)
                         asm volatile("" ::: "memory");  // a fresh load every time round (the builtin is an ordinary read to the compiler)
                         const bool ok = get_tagged<real>(xr, src + (unsigned)k * 64u + (unsigned)lane, tag, &x);
                         if (__builtin_amdgcn_readfirstlane((int)__all(ok))) break;
-                        if (++spins > SWEEP_SPIN_LIMIT ||
+                        if (++spins > sync.spin_limit ||
                             ((spins & 1023u) == 0 && __hip_atomic_load(sync.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
                             if (lane == 0) __hip_atomic_store(sync.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             gave_up = true;
@@ -265,6 +266,7 @@ __global__ void __launch_bounds__(1024)
     const int y0 = 1 + ty * RT, z0 = 1 + tz * RT;
     const bool has_ym = ty > 0, has_yp = ty < gy - 1, has_zm = tz > 0, has_zp = tz < gz - 1;
     const u64 ep = *sync.epoch;
+    const u64 ep_wait = ep + (blockIdx.x == 0 ? sync.fault : 0u);
     const double rd = relax3d_rd<real>(hx2, hy2, hz2);
     const unsigned depthsz = RT * 64, facesz = 2 * depthsz, tilesz = 4 * facesz, bufsz = gridDim.x * tilesz;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, (int)xbytes, 0x00020000);
@@ -407,7 +409,7 @@ __global__ void __launch_bounds__(1024)
         if (s > 0) {
             // ---- the neighbours' black values of sweep s - 1: all loads of a round first, then the tags
             const unsigned base = (unsigned)((s - 1) & 1) * bufsz;
-            const u64 tag = pass_tag<real>(ep, s - 1);
+            const u64 tag = pass_tag<real>(ep_wait, s - 1);
             real x[NF];
             unsigned pending = fneed, spins = 0;
             while (pending && !gave_up) {
@@ -421,7 +423,7 @@ __global__ void __launch_bounds__(1024)
 #pragma unroll
                 for (int i = 0; i < NF; i++)
                     if ((pending & (1u << i)) && __builtin_amdgcn_readfirstlane((int)__all(ok[i]))) pending &= ~(1u << i);
-                if (pending && (++spins > SWEEP_SPIN_LIMIT ||
+                if (pending && (++spins > sync.spin_limit ||
                                 ((spins & 1023u) == 0 && __hip_atomic_load(sync.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0))) {
                     if (lane == 0) __hip_atomic_store(sync.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     gave_up = true;
@@ -484,12 +486,38 @@ __global__ void __launch_bounds__(1024)
 // one-workgroup kernels; above: the level does not fit), all tiles resident at once, a context that has the GPU to itself
 // (thread-ranks and ranks of a communicator launch side by side: co-residency is not given), enough passes to pay for the load
 // and the write-back of the tile.
+// workgroups of a resident kernel that fit a CU at once, asked of the runtime for every variant (the smallest answer counts; 0 = a
+// variant cannot be launched at all on this device: the kernels are not used)
+template <class K>
+static int occupancy_of(K kernel) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kernel, 1024, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return nb;
+}
+static int resident_occupancy(const mgx_ctx* ctx) {
+    if (ctx->resident_occ < 0) {
+        int o = occupancy_of(relax3d_xs_resident_kernel<float>);
+        o = min(o, occupancy_of(relax3d_xs_resident_kernel<double>));
+        o = min(o, occupancy_of(relax3d_xs_resident2_kernel<float, 4>));
+        o = min(o, occupancy_of(relax3d_xs_resident2_kernel<double, 4>));
+        o = min(o, occupancy_of(relax3d_xs_resident2_kernel<float, 8>));
+        o = min(o, occupancy_of(relax3d_xs_resident2_kernel<double, 8>));
+        ctx->resident_occ = o > 0 ? 1 : 0;  // the tile choice below counts on ONE workgroup per CU; more would only relax the test
+    }
+    return ctx->resident_occ;
+}
+
 bool relax3d_resident_takes(const mgx_ctx* ctx, const int n[3], int ncycles) {
     if (!ctx->relax_resident || ctx->nranks > 1 || ctx->local_group) return false;
+    if (ctx->handoff_broken || !ctx->gpu_exclusive) return false;  // a wait has given up before / the GPU is shared: colour passes
     if (n[0] < 33 || n[0] > 129 || n[1] < 9 || n[2] < 9) return false;
+    if (ncycles < ctx->relax_resident_min) return false;
     const int tiles = ceil_div(n[1] - 2, RT) * ceil_div(n[2] - 2, RT);
-    if (tiles > ctx->num_cus || tiles > SWEEP_MAX_WG) return false;
-    return ncycles >= ctx->relax_resident_min;
+    if (tiles > SWEEP_MAX_WG) return false;
+    return tiles <= ctx->num_cus * resident_occupancy(ctx);
 }
 
 // the exchange buffer at the size of the largest level the kernel takes (as many tiles as CUs): [2][tile][4 faces][RT lines][64]
@@ -536,13 +564,13 @@ int relax3d_resident(mgx_ctx* ctx, real* v, const real* f, const int n[3], real 
         int k = left < (1 << 18) ? left : (1 << 18);
         if (per_sweep && left - k == 1) k--;  // never leave a launch of one sweep behind
         if (per_sweep && rt == 4)
-            hipLaunchKernelGGL((relax3d_xs_resident2_kernel<real, 4>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2,
+            MGX_LAUNCH((relax3d_xs_resident2_kernel<real, 4>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2,
                                hy2, hz2, k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)ctx->resident_bytes, sync);
         else if (per_sweep)
-            hipLaunchKernelGGL((relax3d_xs_resident2_kernel<real, 8>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2,
+            MGX_LAUNCH((relax3d_xs_resident2_kernel<real, 8>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2,
                                hy2, hz2, k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)ctx->resident_bytes, sync);
         else
-            hipLaunchKernelGGL((relax3d_xs_resident_kernel<real>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2,
+            MGX_LAUNCH((relax3d_xs_resident_kernel<real>), dim3(gy * gz), dim3(64, 16, 1), 0, ctx->compute, v, f, n[0], n[1], n[2], hx2,
                                hy2, hz2, 2 * k, first ? zero_start : 0, gy, gz, ctx->resident_buf, (unsigned)ctx->resident_bytes, sync);
         left -= k;
     }

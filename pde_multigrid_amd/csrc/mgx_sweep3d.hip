@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
     const int roffSb = min(yS, sy - 1) * g.P;
     const u64 ep = *sync.epoch;  // written by the previous launch's last workgroup: a kernel boundary lies in between
     const u64 epbase = ep << 20;
+    const u64 epwait = (ep + (blockIdx.x == 0 ? sync.fault : 0u)) << 20;  // test hook: see SweepSync
     const u64* dep = nullptr;
     if (NfromNb) dep = sync.flags + (bz * gy + by - 1);
     if (SfromNb) dep = sync.flags + (bz * gy + by + 1);
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
         }                                                                                                                     \
         MGX_STAMP(0);                                                                                                         \
         if (dep && !a_nowait) {                                                                                               \
-            const u64 need = epbase + (u64)(s + 2);                                                                           \
+            const u64 need = epwait + (u64)(s + 2);                                                                           \
             u64 pv_ = __builtin_amdgcn_readfirstlane((unsigned)(pollv >> 32));                                                \
             pv_ = (pv_ << 32) | (u64)__builtin_amdgcn_readfirstlane((unsigned)pollv);                                         \
             unsigned spins = 0;                                                                                               \
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 const u64 t_ = ld_sc1(dep);                                                                                   \
                 pv_ = __builtin_amdgcn_readfirstlane((unsigned)(t_ >> 32));                                                   \
                 pv_ = (pv_ << 32) | (u64)__builtin_amdgcn_readfirstlane((unsigned)t_);                                        \
-                if (++spins > SWEEP_SPIN_LIMIT ||                                                                             \
+                if (++spins > sync.spin_limit ||                                                                             \
                     ((spins & 1023u) == 0 && __hip_atomic_load(sync.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) { \
                     if (lane == 0) __hip_atomic_store(sync.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);           \
                     gave_up = true;                                                                                           \
@@ -462,12 +463,27 @@ __global__ void __launch_bounds__(64 * WX * WY)
 // x = 2 i + q, its x-neighbours are the pair's own black value and that of pair i + 1 (q = 1) or i - 1 (q = 0); its y / z
 // neighbours are the black values of the SAME pair index in the adjacent rows (the parity flips with y and z).  Pair M - 1
 // is the single boundary point x = sx - 1.  ZERO: the input counts as all zeros and is not read (the first sweep on a
-// coarse level, N3/MultiGrid3D.cpp:634 + :626).
-template <class real>
+// coarse level, N3/MultiGrid3D.cpp:634 + :626): nothing is staged, B is never read, the first barrier is gone.
+// LDS words read, per phase, against the words written before them (t < n covers every index of a phase: the host admits a
+// tile only if its (TY + 2)(TZ + 2) M red items fit 4 per thread):
+//   red, interior point of row (y, z) in [ra, rb) x [sa, sb): B at pair i, i +- 1 (x >= 1 resp. x <= sx - 2 keeps i +- 1 in
+//     [0, M)), rows y +- 1 in [ya, yb), planes z +- 1 in [za, zb) -- interior means 1 <= y <= sy - 2, so y - 1 >= max(y0 - 2, 0)
+//     = ya and y + 1 <= min(y1, sy - 1) < yb, likewise z; staging writes EVERY (i, y, z) of [0, M) x [ya, yb) x [za, zb),
+//     including the pair without a point (2 i + q = sx: 0);
+//   black, point of the tile: Rd at pair i, i +- 1, rows y +- 1 in [y0 - 1, y1] = [ra, rb), planes likewise; the red phase
+//     writes Rd for EVERY item (kinds 0 ... 3: no point, boundary value, halo, own).
+// Round 3 shipped ZERO as a run-time flag because a template-specialised form had produced wrong values next to boundary
+// faces that depended on what the previous launch had left in LDS.  That form was never committed and cannot be diffed; this
+// one is specialised again and runs the whole GPU suite with the LDS of every CU filled with NaN patterns before EVERY
+// launch (mgx_test_set_lds_poison, tests/conftest.py; tests/test_gpu_sweep.py: test_lds_poisoning_reaches_every_cu proves
+// the poison arrives, test_mid_from_zero_specialisation_at_129_rows is the case that had failed): no read of an unwritten
+// word exists in it.  The likely cause then: the tile rule of that day admitted 129-point rows with 8 x 8 tiles, 6500 red
+// items against the 4096 that 1024 threads x UC = 4 cover -- Rd entries beyond that were never written, and the black
+// points reading them sit in the last rows / planes of a tile; sweep3d_mid_tile now bounds the items itself.
+template <class real, bool ZERO>
 __global__ void __launch_bounds__(1024) sweep3d_xs_mid_kernel(const real* __restrict__ vin, real* __restrict__ vout,
                                                               const real* __restrict__ f, int sx, int sy, int sz, real hx2, real hy2,
-                                                              real hz2, int c0, int TY, int TZ, int gy, int zero) {
-    const bool ZERO = zero != 0;  // a run-time flag on purpose: see the note at step 1
+                                                              real hz2, int c0, int TY, int TZ, int gy) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     const double rd = relax3d_rd<real>(hx2, hy2, hz2);
     const Geo<XSplit, real> g(sx, sy);
@@ -537,12 +553,10 @@ __global__ void __launch_bounds__(1024) sweep3d_xs_mid_kernel(const real* __rest
             }
         }
     }
-    // 1. the old black values of the rows [ya, yb) x [za, zb) (ZERO: zeros, nothing is read), in chunks of U per thread: first all
-    // loads of a chunk, then its LDS stores.  ZERO is a run-time flag: as a template parameter the specialised kernel gave wrong
-    // values next to boundary faces whenever the previous launch had left non-zero data in LDS (hipcc 7.2; found by sweep_once
-    // against the oracle, not understood) -- the generic code path with two selects is bit-exact.
+    // 1. the old black values of the rows [ya, yb) x [za, zb), in chunks of U per thread: first all loads of a chunk, then its
+    // LDS stores.  ZERO: nothing is staged and B is never read -- every old value is the constant 0.
     constexpr int U = 6;
-    {
+    if (!ZERO) {
         const int NY = yb - ya, n = (zb - za) * NY * M;
         const SmallDiv dNY(NY);
         for (int base = tid; base < n; base += nt * U) {
@@ -557,15 +571,15 @@ __global__ void __launch_bounds__(1024) sweep3d_xs_mid_kernel(const real* __rest
                     const int r = dM(t), i = t - r * M, zz = dNY(r), yy = r - zz * NY, y = ya + yy, z = za + zz;
                     const int q = (c0 + 1 + y + z) & 1;
                     li[u] = i + yy * BW + zz * BP;
-                    if (!ZERO && 2 * i + q < sx) tmp[u] = vin[g.row(y, z) + q * H + i];
+                    if (2 * i + q < sx) tmp[u] = vin[g.row(y, z) + q * H + i];
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; u++)
                 if (li[u] >= 0) B[li[u]] = tmp[u];
         }
+        __syncthreads();
     }
-    __syncthreads();
     // 2. red on the tile and one row / plane around it (boundary points keep their value)
 #pragma unroll
     for (int u = 0; u < UC; u++) {
@@ -573,7 +587,10 @@ __global__ void __launch_bounds__(1024) sweep3d_xs_mid_kernel(const real* __rest
         real val = (real)0;
         if (!ZERO && rkind[u] == 1) val = fr[u];
         if (rkind[u] >= 2) {
-            {
+            if (ZERO) {
+                const real z = (real)0;
+                val = relax3d_point_rd<real>(z, z, z, z, z, z, fr[u], hx2, hy2, hz2, rd);
+            } else {
                 const int q = rbi[u] & 1;
                 const real* b = B + (rbi[u] >> 1);  // the pair's own black value (x + 1 - 2 q)
                 const real side = q ? b[1] : b[-1];
@@ -648,6 +665,8 @@ int sweep_state(mgx_ctx* ctx, SweepSync* out) {
     void* adev = nullptr;
     MGX_HIP(hipHostGetDevicePointer(&adev, ctx->sweep_abort, 0));
     out->abort = (unsigned*)adev;
+    out->spin_limit = ctx->sync_spin_limit;
+    out->fault = ctx->handoff_fault;
     return MGX_OK;
 }
 
@@ -655,16 +674,18 @@ constexpr int SWEEP_MID = 1;  // shape code of sweep3d_xs_mid_kernel
 
 // tile (TY rows x TZ planes) of the mid-level kernel: at least ~128 workgroups where the level has them, LDS within 150 KB
 template <class real>
-static bool sweep3d_mid_tile(int sx, int sy, int sz, int* TY, int* TZ) {
+static bool sweep3d_mid_tile(int sx, int sy, int sz, int* TY, int* TZ, int max_row = 65) {
     // measured (tools/level_timing.py, 513^3 cycle, MI355X): 33^3 level 44 -> 37 us per visit, 65^3 equal, 129^3 78 -> 100 us (256
     // workgroups of 1024 threads doing 2.6 x the arithmetic lose against two 5 us passes): rows of at most 65 points only
-    if (sx > 65 || sx < 33 || sy < 9 || sz < 9) return false;
+    // ("relax3d.fused_mid" = 2 lets rows of 129 points in: the size at which a specialised from-zero form once failed, kept testable)
+    if (sx > max_row || sx < 33 || sy < 9 || sz < 9) return false;
     int ty = 8, tz = 8;
     auto wgs = [&]() { return ceil_div(sy - 2, ty) * ceil_div(sz - 2, tz); };
     auto bytes = [&]() { return (size_t)((sx + 1) / 2) * ((ty + 4) * (tz + 4) + (ty + 2) * (tz + 2)) * sizeof(real); };
-    if (wgs() < 128 || bytes() > 150 * 1024) tz = 4;
+    auto items = [&]() { return (ty + 2) * (tz + 2) * ((sx + 1) / 2); };  // red items of a tile: at most 4 per thread of 1024
+    if (wgs() < 128 || bytes() > 150 * 1024 || items() > 4096) tz = 4;
     if (wgs() < 128 && sy - 2 > 4) ty = 4;
-    if (bytes() > 150 * 1024) return false;
+    if (bytes() > 150 * 1024 || items() > 4096) return false;
     *TY = ty;
     *TZ = tz;
     return true;
@@ -674,11 +695,15 @@ static bool sweep3d_mid_tile(int sx, int sy, int sz, int* TY, int* TZ) {
 template <class real>
 static int sweep3d_shape(const mgx_ctx* ctx, int sx, int sy, int sz) {
     int ty, tz;
-    if (ctx->sweep_mid && sweep3d_mid_tile<real>(sx, sy, sz, &ty, &tz)) return SWEEP_MID;
+    if (ctx->sweep_mid && sweep3d_mid_tile<real>(sx, sy, sz, &ty, &tz, ctx->sweep_mid >= 2 ? 129 : 65)) return SWEEP_MID;
     if (!ctx->sweep_fused || ctx->nranks > 1 || ctx->local_group) return 0;  // thread-ranks share one GPU: co-residency is not given
+    if (ctx->handoff_broken || !ctx->gpu_exclusive) return 0;
     const int M = (sx + 1) / 2;
     if (M - 1 != 256) return 0;          // tiles span the x-extent: 513-point rows (4 waves of 64 pairs)
     if (sy - 2 < 64 || sz - 2 < 64) return 0;
+    // one workgroup per CU (132 KB of LDS), all resident together: a level with more 8-row tiles than CUs (513 x 4097 x N on 256 CUs)
+    // runs colour passes -- the same test as sweep3d_launch_shape's, so that the takes-predicates and the launch agree
+    if (ceil_div(sy - 2, 8) > (ctx->num_cus < SWEEP_MAX_WG ? ctx->num_cus : SWEEP_MAX_WG)) return 0;
     return 424;
 }
 
@@ -707,10 +732,10 @@ static int sweep3d_launch_shape(mgx_ctx* ctx, const real* vin, real* vout, const
         void* ws = nullptr;
         MGX_TRY_RET(workspace(ctx, (size_t)gy * gz * WX * WY * 8 * sizeof(long long), &ws));
         if (ctx->sweep_ilv)
-            hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, true, 1, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb,
+            MGX_LAUNCH((sweep3d_xs_kernel<real, WX, WY, R, D, true, 1, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb,
                                ze, hx2, hy2, hz2, c0, zchunk, gy, xcd, sync, (long long*)ws, ctx->sweep_dbg >> 1);
         else
-            hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, true, 1>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb, ze,
+            MGX_LAUNCH((sweep3d_xs_kernel<real, WX, WY, R, D, true, 1>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb, ze,
                                hx2, hy2, hz2, c0, zchunk, gy, xcd, sync, (long long*)ws, ctx->sweep_dbg >> 1);
         return MGX_OK;
     }
@@ -718,18 +743,18 @@ static int sweep3d_launch_shape(mgx_ctx* ctx, const real* vin, real* vout, const
     long long* const nodbg = nullptr;
     if (ctx->sweep_ilv) {  // memory instructions interleaved with the arithmetic ("relax3d.fused_ilv")
         if (fnt)
-            hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, true, 0, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb,
+            MGX_LAUNCH((sweep3d_xs_kernel<real, WX, WY, R, D, true, 0, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb,
                                ze, hx2, hy2, hz2, c0, zchunk, gy, xcd, sync, nodbg, 0);
         else
-            hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, false, 0, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb,
+            MGX_LAUNCH((sweep3d_xs_kernel<real, WX, WY, R, D, false, 0, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb,
                                ze, hx2, hy2, hz2, c0, zchunk, gy, xcd, sync, nodbg, 0);
         return MGX_OK;
     }
     if (fnt)
-        hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb, ze, hx2,
+        MGX_LAUNCH((sweep3d_xs_kernel<real, WX, WY, R, D, true>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb, ze, hx2,
                            hy2, hz2, c0, zchunk, gy, xcd, sync);
     else
-        hipLaunchKernelGGL((sweep3d_xs_kernel<real, WX, WY, R, D, false>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb, ze, hx2,
+        MGX_LAUNCH((sweep3d_xs_kernel<real, WX, WY, R, D, false>), grid, block, 0, ctx->compute, vin, vout, f, sx, sy, sz, zb, ze, hx2,
                            hy2, hz2, c0, zchunk, gy, xcd, sync);
     return MGX_OK;
 }
@@ -738,19 +763,24 @@ template <class real>
 static int sweep3d_mid_launch(mgx_ctx* ctx, const real* vin, real* vout, const real* f, int sx, int sy, int sz, real hx2, real hy2, real hz2,
                               bool zero) {
     int TY = 8, TZ = 8;
-    MGX_REQUIRE(sweep3d_mid_tile<real>(sx, sy, sz, &TY, &TZ), MGX_ERR_SIZE, "sweep3d_mid: level %d x %d x %d does not take the kernel", sx, sy, sz);
+    MGX_REQUIRE(sweep3d_mid_tile<real>(sx, sy, sz, &TY, &TZ, 129), MGX_ERR_SIZE, "sweep3d_mid: level %d x %d x %d does not take the kernel", sx, sy, sz);
     const size_t lds = (size_t)((sx + 1) / 2) * ((TY + 4) * (TZ + 4) + (TY + 2) * (TZ + 2)) * sizeof(real);
     const int gy = ceil_div(sy - 2, TY), gz = ceil_div(sz - 2, TZ);
     const int threads = (size_t)TY * TZ * ((sx + 1) / 2) >= 2048 ? 1024 : 512;
     MGX_REQUIRE((TY + 2) * (TZ + 2) * ((sx + 1) / 2) <= 4 * threads, MGX_ERR_SIZE, "sweep3d_mid: tile %d x %d of %d-point rows has more than 4 items per thread",
                 TY, TZ, sx);
     if (lds > 64 * 1024) {
-        MGX_HIP(hipFuncSetAttribute((const void*)sweep3d_xs_mid_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MGX_HIP(hipFuncSetAttribute((const void*)sweep3d_xs_mid_kernel<real, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MGX_HIP(hipFuncSetAttribute((const void*)sweep3d_xs_mid_kernel<real, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "sweep3d_xs_mid_kernel<%s>%s", sizeof(real) == 8 ? "double" : "float",
              zero ? " (from zero)" : "");
-    hipLaunchKernelGGL((sweep3d_xs_mid_kernel<real>), dim3(gy * gz), dim3(threads), lds, ctx->compute, vin, vout, f, sx, sy, sz, hx2, hy2, hz2,
-                       0, TY, TZ, gy, zero ? 1 : 0);
+    if (zero)
+        MGX_LAUNCH((sweep3d_xs_mid_kernel<real, true>), dim3(gy * gz), dim3(threads), lds, ctx->compute, vin, vout, f, sx, sy, sz, hx2, hy2,
+                   hz2, 0, TY, TZ, gy);
+    else
+        MGX_LAUNCH((sweep3d_xs_mid_kernel<real, false>), dim3(gy * gz), dim3(threads), lds, ctx->compute, vin, vout, f, sx, sy, sz, hx2, hy2,
+                   hz2, 0, TY, TZ, gy);
     return MGX_OK;
 }
 
@@ -793,7 +823,7 @@ int relax3d_xs_pp(mgx_ctx* ctx, real* v, real* w, const real* f, const int n[3],
         k--;
     }
     if (!w_rim_valid) {
-        hipLaunchKernelGGL((copy_rim3d_xs_kernel<real>), dim3(n[2], 4), dim3(256), 0, ctx->compute, (const real*)v, w, n[0], n[1], n[2]);
+        MGX_LAUNCH((copy_rim3d_xs_kernel<real>), dim3(n[2], 4), dim3(256), 0, ctx->compute, (const real*)v, w, n[0], n[1], n[2]);
         MGX_LAUNCH_CHECK();
     }
     for (; k > 0; k -= 2) {
@@ -830,7 +860,7 @@ int relax3d_xs_from_zero_pp(mgx_ctx* ctx, real* v, real* w, const real* f, const
     if (shape != SWEEP_MID) return relax3d_xs_from_zero<real>(ctx, v, f, n, h, ncycles, rim_is_zero);
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
     if (!w_rim_valid) {  // the boundary of v is zero: so must be w's
-        hipLaunchKernelGGL((copy_rim3d_xs_kernel<real>), dim3(n[2], 4), dim3(256), 0, ctx->compute, (const real*)v, w, n[0], n[1], n[2]);
+        MGX_LAUNCH((copy_rim3d_xs_kernel<real>), dim3(n[2], 4), dim3(256), 0, ctx->compute, (const real*)v, w, n[0], n[1], n[2]);
         MGX_LAUNCH_CHECK();
     }
     for (int k = 0; k < ncycles; k += 2) {
@@ -908,10 +938,33 @@ int mgx_sweep_debug_read(mgx_ctx* ctx, long long* host, size_t count) {
 // launch are garbage).  Meaningful after a synchronisation (mgx_ctx_sync calls it).
 int mgx_ctx_check(mgx_ctx* ctx) {
     MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
-    if (ctx->sweep_abort && *(volatile unsigned*)ctx->sweep_abort)
+    if (ctx->sweep_abort && *(volatile unsigned*)ctx->sweep_abort) {
+        ctx->handoff_broken = 1;  // from now on: colour passes
         return mgx::fail(MGX_ERR_HIP, "a kernel whose workgroups wait for each other (one-launch sweep, resident Relax) gave up waiting for a "
-                                      "neighbouring workgroup (workgroups not resident together?); its results are invalid -- set "
-                                      "\"relax3d.fused\" and \"relax3d.resident\" to 0");
+                                      "neighbouring workgroup (is the GPU shared with another context or process? then set \"gpu.exclusive\" "
+                                      "to 0); the results of that launch are invalid.  This context now runs colour passes instead; "
+                                      "mgx_ctx_clear_abort clears the condition");
+    }
+    return MGX_OK;
+}
+
+int mgx_ctx_clear_abort(mgx_ctx* ctx, int reenable) {
+    MGX_REQUIRE(ctx, MGX_ERR_INVALID, "ctx is NULL");
+    MGX_USE(ctx);
+    MGX_HIP(hipStreamSynchronize(ctx->compute));
+    MGX_HIP(hipStreamSynchronize(ctx->comm));
+    if (ctx->sweep_abort && *(volatile unsigned*)ctx->sweep_abort) ctx->handoff_broken = 1;
+    if (ctx->sweep_dev) {
+        // every workgroup of an aborted launch still ran to its end (the finished-counter wrapped, the epoch advanced), but nothing is
+        // taken on trust here: progress words and counter cleared, the epoch moved past anything a stale tag could carry
+        mgx::u64 ep = 0;
+        MGX_HIP(hipMemcpy(&ep, ctx->sweep_dev, sizeof ep, hipMemcpyDeviceToHost));
+        MGX_HIP(hipMemset(ctx->sweep_dev, 0, 64 + sizeof(mgx::u64) * mgx::SWEEP_MAX_WG));
+        ep += 2;
+        MGX_HIP(hipMemcpy(ctx->sweep_dev, &ep, sizeof ep, hipMemcpyHostToDevice));
+    }
+    if (ctx->sweep_abort) *(volatile unsigned*)ctx->sweep_abort = 0;
+    if (reenable) ctx->handoff_broken = 0;
     return MGX_OK;
 }
 }

@@ -5,8 +5,12 @@
 // and then one lane stores the workgroup's progress word (sc1); the consumer polls that word (sc1 load, bounded spin) and only
 // then issues its own sc1 loads of the data.  Words carry a launch epoch kept in device memory and advanced by the last
 // workgroup of a launch, so nothing is cleared between launches or graph replays.  All workgroups of such a launch must be
-// resident together (the host checks grid <= CUs at one workgroup per CU); a wait that does not end sets the context's
-// host-visible abort word and gives up, so every wave terminates (mgx_ctx_check / mgx_ctx_sync report it).
+// resident together: the host checks grid <= CUs x the kernel's occupancy (hipOccupancyMaxActiveBlocksPerMultiprocessor) and
+// ASSUMES the context has the GPU to itself ("gpu.exclusive", default 1) -- another process or context launching large
+// workgroups at the same time can keep part of the grid from becoming resident.  A wait that does not end within
+// sync.spin_limit polls sets the context's host-visible abort word and gives up, and every wave that polls sees the word within
+// 1024 polls and gives up too, so the launch terminates; mgx_ctx_check / mgx_ctx_sync report it, the context stops using these
+// kernels (handoff_broken: colour passes from then on) and mgx_ctx_clear_abort makes it usable again.
 #pragma once
 #include "mgx_internal.hpp"
 
@@ -19,6 +23,8 @@ struct SweepSync {
     u64* epoch;       // launch counter
     unsigned* done;   // workgroups of the current launch that have finished
     unsigned* abort;  // host-mapped: != 0 once a wait has given up
+    unsigned spin_limit;  // polls (each ~1 us) before a wait gives up ("sync.spin_limit")
+    unsigned fault;       // test hook ("test.handoff_fault"): workgroup 0 waits for tags of epoch + fault, which nobody writes
 };
 
 template <class T>
@@ -30,7 +36,7 @@ __device__ __forceinline__ void st_sc1(T* p, T v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-constexpr unsigned SWEEP_SPIN_LIMIT = 1u << 21;  // polls (each ~1 us) before a wait gives up
+constexpr unsigned SWEEP_SPIN_LIMIT = 1u << 21;  // default of "sync.spin_limit"
 
 constexpr int SWEEP_MAX_WG = 2048;  // progress words per context
 

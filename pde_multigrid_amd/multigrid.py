@@ -95,6 +95,10 @@ class Context:
     def set_param(self, name, value):
         check(lib.mgx_ctx_set_param(self._h, name.encode(), C.c_int(int(value))))
 
+    def clear_abort(self, reenable=False):
+        """after sync() reported a given-up wait between workgroups: clear the condition (mgx_ctx_clear_abort)"""
+        check(lib.mgx_ctx_clear_abort(self._h, C.c_int(1 if reenable else 0)))
+
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)
         p = self.malloc(arr.nbytes)

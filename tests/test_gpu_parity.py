@@ -902,3 +902,29 @@ def test_2d_mean_absolute_error_metric(ctx):
     got = mg.MeanAbsoluteError(0)
     assert abs(got - want) <= 1e-6 * max(1.0, want)
     mg.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_3d_public_relax_on_coarse_level_with_nonzero_boundary_then_cycle(ctx, dtype):
+    """public-operator use on a coarse level must not leave a stale boundary in the level's ping-pong partner: upload a v with a
+    non-zero boundary into levels 1 and 2 (65^3, 33^3: the one-launch-per-sweep levels), call Relax there (the partner's boundary
+    now equals that non-zero one), then run V-cycles from level 0 -- the reference zeroes the coarse v including its boundary
+    (N3/MultiGrid3D.cpp:634), so the result is the oracle's plain cycle"""
+    n3, rg = (129, 129, 129), [-1, 1, 0, 2, 0.5, 3]
+    rng = np.random.default_rng(77)
+    v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
+    for v1 in (2, 1):  # way down: fused smooth+residual+restrict resp. relax_from_zero_pp first
+        mg = P.MultiGrid3D(ctx, n3, rg, dtype)
+        mg.upload_v(0, v)
+        mg.upload_f(0, f)
+        for lvl in (1, 2):
+            m = mg.size(lvl)
+            mg.upload_v(lvl, rng.uniform(1, 2, O.shape(m)).astype(dtype))
+            mg.upload_f(lvl, rng.uniform(-1, 1, O.shape(m)).astype(dtype))
+            mg.Relax(lvl, 2)
+        mg.VCycle(0, v1, 2)
+        mg.VCycle(0, v1, 2)
+        want = O.cycle3d(n3, rg, mode=0, v1=v1, v2=2, reps=2, v=v, f=f, dtype=dtype)
+        assert bits_equal(mg.download_v(0), want), v1
+        mg.close()

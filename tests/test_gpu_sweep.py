@@ -209,3 +209,53 @@ def test_hierarchy_relax_uses_sweep_and_keeps_boundary(ctx):
     got = mg.download_v(0)
     mg.close()
     assert bits_equal(got, O.relax3d((n, 129, 129), RG, v, f, 5, dtype=np.float64))
+
+
+def test_lds_poisoning_reaches_every_cu(ctx):
+    """the suite runs with mgx_test_set_lds_poison(1) (tests/conftest.py): every launch is preceded by a launch that fills each
+    CU's LDS with NaN patterns.  Self-test: a probe that reads all 160 KB of LDS on every CU without writing sees nothing but the
+    pattern -- so a kernel that reads an LDS word before writing it computes with NaNs and fails its parity test."""
+    import ctypes
+    import os
+    if os.environ.get("MGX_POISON_LDS", "1") == "0":
+        pytest.skip("poisoning switched off")
+    frac = ctypes.c_double(-1.0)
+    for _ in range(3):
+        P.check(P.lib.mgx_test_lds_probe(ctx._h, ctypes.byref(frac)))
+        assert frac.value == 1.0, frac.value
+    P.lib.mgx_test_set_lds_poison(0)
+    try:
+        ctx.sync()
+        P.check(P.lib.mgx_test_lds_probe(ctx._h, ctypes.byref(frac)))  # the previous probe wrote nothing: still all pattern
+        assert frac.value == 1.0, frac.value
+        v, f = _data((65, 65, 65), np.float64, seed=3)
+        P.ops3dxs.relax_pp(ctx, v, f, (65, 65, 65), RG, 2)  # a real kernel overwrites LDS on the CUs it runs on
+        P.check(P.lib.mgx_test_lds_probe(ctx._h, ctypes.byref(frac)))
+        assert frac.value < 1.0, frac.value
+    finally:
+        P.lib.mgx_test_set_lds_poison(1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_mid_from_zero_specialisation_at_129_rows(ctx, dtype):
+    """the case that failed in round 3 with a template-specialised from-zero form of sweep3d_xs_mid_kernel ("wrong values next to
+    boundary faces whenever the previous launch had left non-zero data in LDS"): 129^3, two sweeps from zero.  The kernel is
+    specialised on ZERO again (nothing staged, B never read); with LDS poisoned before every launch a read of an unwritten word
+    cannot pass.  "relax3d.fused_mid" = 2 lets rows of 129 points into the kernel (the default keeps them on colour passes)."""
+    n3 = (129, 129, 129)
+    v, f = _data(n3, dtype, seed=1)
+    v[0], v[-1], v[:, 0], v[:, -1], v[:, :, 0], v[:, :, -1] = 0, 0, 0, 0, 0, 0
+    zero = np.zeros_like(v)
+    ctx.set_param("relax3d.fused_mid", 2)
+    ctx.set_param("relax3d.resident", 0)
+    try:
+        for ncycles in (2, 4):
+            got = P.ops3dxs.relax_from_zero_pp(ctx, v, f, n3, RG, ncycles, True)
+            assert ctx.last_relax_kernel().startswith("sweep3d_xs_mid_kernel"), ctx.last_relax_kernel()
+            assert bits_equal(got, O.relax3d(n3, RG, zero, f, ncycles, dtype=dtype)), ncycles
+        got = P.ops3dxs.relax_pp(ctx, v, f, n3, RG, 2)
+        assert ctx.last_relax_kernel().startswith("sweep3d_xs_mid_kernel"), ctx.last_relax_kernel()
+        assert bits_equal(got, O.relax3d(n3, RG, v, f, 2, dtype=dtype))
+    finally:
+        ctx.set_param("relax3d.fused_mid", 1)
+        ctx.set_param("relax3d.resident", 1)
