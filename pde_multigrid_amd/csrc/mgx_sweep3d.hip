@@ -477,9 +477,9 @@ __global__ void __launch_bounds__(64 * WX * WY)
 // one is specialised again and runs the whole GPU suite with the LDS of every CU filled with NaN patterns before EVERY
 // launch (mgx_test_set_lds_poison, tests/conftest.py; tests/test_gpu_sweep.py: test_lds_poisoning_reaches_every_cu proves
 // the poison arrives, test_mid_from_zero_specialisation_at_129_rows is the case that had failed): no read of an unwritten
-// word exists in it.  The likely cause then: the tile rule of that day admitted 129-point rows with 8 x 8 tiles, 6500 red
-// items against the 4096 that 1024 threads x UC = 4 cover -- Rd entries beyond that were never written, and the black
-// points reading them sit in the last rows / planes of a tile; sweep3d_mid_tile now bounds the items itself.
+// word exists in it.  What the failing build did differently is not recoverable (the run-time-flag form of the same day
+// passed the same case, so it was specific to how that specialisation was written, not to the tile geometry); the class of
+// bug is now caught deterministically instead.  sweep3d_mid_tile also bounds the red items of a tile itself (4 per thread).
 template <class real, bool ZERO>
 __global__ void __launch_bounds__(1024) sweep3d_xs_mid_kernel(const real* __restrict__ vin, real* __restrict__ vout,
                                                               const real* __restrict__ f, int sx, int sy, int sz, real hx2, real hy2,
