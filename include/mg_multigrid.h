@@ -39,9 +39,12 @@ extern "C" {
 
 /* Which planes of a level one rank of a z-slab decomposition holds (global plane indices).  Pure host
  * arithmetic; also used by the CPU emulation test of the decomposition. */
+#define MG_DEEP_GHOSTS 6      /* ghost planes on either side of a slab of >= MG_DEEP_MIN_PLANES planes */
+#define MG_DEEP_MIN_PLANES 8
 typedef struct mgSlabPlan {
     int zlo, zhi;   /* owned planes [zlo, zhi); the last rank also owns the boundary plane sizeZ-1 */
-    int glo, ghi;   /* ghost planes below (2 on ranks > 0) and above (1 on ranks < P-1) */
+    int glo, ghi;   /* ghost planes below (ranks > 0) and above (ranks < P-1): MG_DEEP_GHOSTS each on slabs of at least */
+                    /* MG_DEEP_MIN_PLANES planes, otherwise 2 below and 1 above */
     int zoff, nzl;  /* local array = global planes [zoff, zoff + nzl), zoff = zlo - glo */
     int ubeg, uend; /* planes the smoother updates: owned and interior, [max(zlo,1), min(zhi, sizeZ-1)) */
 } mgSlabPlan;
@@ -148,6 +151,7 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         mgSlabPlan plan;                                                                                 \
         real h_x, h_y, h_z;                                                                              \
         real x_a, y_a, z_a;                                                                              \
+        int level;      /* its index in mgDistMultiGrid3D::slabs */                                      \
     } mgSlab3D_##R;                                                                                      \
     typedef struct mgDistMultiGrid3D_##R {                                                               \
         mgSlab3D_##R** slabs;      /* levels 0 .. numDist-1 */                                           \
@@ -183,6 +187,20 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out);
         int pack_halos;                                                                                  \
         real* d_stage;                                                                                   \
         size_t stage_half;                                                                               \
+        /* Communication-avoiding schedule (public knob): levels whose slabs have at least ca_min_planes */ \
+        /* planes (default 16; 0 = never) exchange ghost planes of v ONCE PER Relax CALL (4 deep for two */ \
+        /* sweeps) instead of once per colour pass: the first ghost planes are relaxed redundantly, the */ \
+        /* owner's expression on the owner's inputs (same bits), the valid region shrinking by one plane */ \
+        /* per pass.  Thinner levels keep one exchange per colour pass.                                  */ \
+        int ca_min_planes;                                                                               \
+        /* internal: how many ghost planes of v / f on either side of a level's slab hold current values */ \
+        /* (the same number on every rank; >= MG_DEEP_GHOSTS: all of them); consumers ask for what they */ \
+        /* read and an exchange happens only when that is not there                                     */ \
+        signed char gv[MG_MAX_LEVELS], gf[MG_MAX_LEVELS];                                                \
+        int comm_pending;          /* an exchange is in flight on the comm stream; nothing may touch ghost */ \
+                                   /* planes before mgx_comm_wait                                       */ \
+        /* halo exchanges + collectives enqueued since creation (bench.py: exchanges per cycle)          */ \
+        long long n_exchanges;                                                                           \
     } mgDistMultiGrid3D_##R;                                                                             \
     int mgDistMultiGrid3D_##R##_create(mgx_ctx* ctx, const int finestGridSizeXYZ[3], const real range[6], \
                                        int min_planes, mgDistMultiGrid3D_##R** out);                     \

@@ -25,6 +25,14 @@ static inline int mg_fail(int status, const char* fmt, ...) {
     return status;
 }
 
+/* MG_CA_TRACE=1 in the environment: the slab driver prints the launches and exchanges of its communication-avoiding
+ * schedule (level, pass, plane ranges) to stderr -- a debugging aid, read once */
+static inline int mg_ca_trace(void) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MG_CA_TRACE"); on = e && *e && *e != '0'; }
+    return on;
+}
+
 #define MG_TRY(expr)            \
     do {                        \
         int st_ = (expr);       \

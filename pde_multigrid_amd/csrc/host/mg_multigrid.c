@@ -39,8 +39,12 @@ int mg_slab_plan(int sizeZ_level, int rank, int nranks, mgSlabPlan* out) {
     if (N % nranks != 0) return mg_fail(MGX_ERR_SIZE, "mg_slab_plan: %d cells do not divide over %d ranks", N, nranks);
     out->zlo = rank * (N / nranks);
     out->zhi = (rank + 1) * (N / nranks) + (rank == nranks - 1 ? 1 : 0); /* the last rank also owns boundary plane N */
-    out->glo = rank > 0 ? 2 : 0;
-    out->ghi = rank < nranks - 1 ? 1 : 0;
+    /* ghost planes: slabs of at least MG_DEEP_MIN_PLANES planes carry MG_DEEP_GHOSTS on either side (the communication-avoiding
+     * schedule of mg_dist3d.inc relaxes the first ghost planes redundantly and exchanges once per Relax call); thinner slabs
+     * the 2 below / 1 above of the exchange-per-colour-pass schedule.  The same on every rank of a level. */
+    const int deep = (N / nranks) >= MG_DEEP_MIN_PLANES;
+    out->glo = rank > 0 ? (deep ? MG_DEEP_GHOSTS : 2) : 0;
+    out->ghi = rank < nranks - 1 ? (deep ? MG_DEEP_GHOSTS : 1) : 0;
     out->zoff = out->zlo - out->glo;
     out->nzl = (out->zhi - out->zlo) + out->glo + out->ghi;
     out->ubeg = out->zlo > 1 ? out->zlo : 1;     /* global planes the smoother updates: owned and interior */

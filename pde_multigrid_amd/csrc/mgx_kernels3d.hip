@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(64 * WX * WY)
 // complete, and a wave has memory requests in flight all the time instead of only while it waits for them.
 //
 // (CORR on a z-slab: vin / f / vout and `coarse` are local arrays; the host shifts `coarse` so that local fine plane z
-// interpolates from coarse planes z >> 1 (+1), hands in szg = global plane count - global index of local plane 0, and
+// interpolates from coarse planes z >> 1 (+1), hands in szg = global plane count - global index of local plane 0, zg0 = that
+// global index (local plane 0 is the grid's boundary plane, which carries no correction, only where zg0 = 0), and
 // ckmax = the last coarse plane (in that indexing) that exists locally: staging requests are clamped to it.)
 // VAR = 2 ("CORR"): the pass reads the other colour THROUGH the coarse-grid correction -- every own-column value of the
 // other colour that enters the registers gets e = Interpolate(coarse)(x, y, z) added if it is an interior point: exactly
@@ -428,7 +429,7 @@ template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0>
 __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whatever the shape: 8-wave workgroups run two to a CU
     relax3d_xs_pipe_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                            int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
-                           int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0, int ckmax = 0) {
+                           int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0, int ckmax = 0, int zg0 = 0) {
     constexpr bool CORR = VAR == 2;
     // VAR == 3: the BLACK pass of the first sweep of a level that counts as all zeros (zero boundary in memory), with the red
     // pass before it folded in: the caller hands f as `vin`; every other-colour value the pass reads is the red pass's result
@@ -654,7 +655,7 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
         for (int r = 0; r < R; r++)
             if (own[r]) {
                 const int qr = q ^ (r & 1), y = y0 + r;
-                if (z0 - 1 >= 1 && (qr | j)) cp[r] = cp[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + qr, y, z0 - 1);
+                if (z0 - 1 + zg0 >= 1 && (qr | j)) cp[r] = cp[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + qr, y, z0 - 1);
                 if ((1 - qr) | j) cc[r] = cc[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + 1 - qr, y, z0);
                 if (z0 + 1 <= szg - 2 && (qr | j)) cu[r] = cu[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j + qr, y, z0 + 1);
             }
@@ -853,7 +854,7 @@ template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0>
 __global__ void __launch_bounds__(64 * WX * WY)
     relax3d_xs_pipe_v2_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                               int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
-                              int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0, int ckmax = 0) {
+                              int xcd_mode, const real* __restrict__ coarse = nullptr, int cx = 0, int cy = 0, int szg = 0, int ckmax = 0, int zg0 = 0) {
     typedef typename Vec2T<real>::type vec2;
     constexpr bool CORR = VAR == 2;
     static_assert(!CORR || R == 2, "the correcting variant is written for 2 rows per lane");
@@ -1036,12 +1037,12 @@ __global__ void __launch_bounds__(64 * WX * WY)
                 if (qr == 1 && lane == 63) xc[r] = xc[r] + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + 4, y, z0);
             }
             if (own0[r]) {
-                if (z0 - 1 >= 1 && (qr | j0)) cp[r].x = cp[r].x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + qr, y, z0 - 1);
+                if (z0 - 1 + zg0 >= 1 && (qr | j0)) cp[r].x = cp[r].x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + qr, y, z0 - 1);
                 if ((1 - qr) | j0) cc[r].x = cc[r].x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + 1 - qr, y, z0);
                 if (z0 + 1 <= szg - 2 && (qr | j0)) cu[r].x = cu[r].x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + qr, y, z0 + 1);
             }
             if (own1[r]) {
-                if (z0 - 1 >= 1) cp[r].y = cp[r].y + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + qr, y, z0 - 1);
+                if (z0 - 1 + zg0 >= 1) cp[r].y = cp[r].y + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + qr, y, z0 - 1);
                 cc[r].y = cc[r].y + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + 1 - qr, y, z0);
                 if (z0 + 1 <= szg - 2) cu[r].y = cu[r].y + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + qr, y, z0 + 1);
             }
@@ -3035,7 +3036,7 @@ static void corr_pset_launch(mgx_ctx* ctx, real* v, int sx, int sy, int fzoff, c
 // ckmax = last plane of coarse_sh that exists; colour = 0 + parity of the slab's global offset
 template <class real>
 static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zb, int ze, real hx2, real hy2, real hz2, int colour,
-                            const real* coarse_sh, int cx, int cy, int szl, int ckmax) {
+                            const real* coarse_sh, int cx, int cy, int szl, int ckmax, int zg0 = 0) {
     const int M = (sx + 1) / 2;
     int zchunk = ctx->relax_zchunk;
     if (corr_tile_pairs<real>(ctx, sx) == 256) {  // fp32, wide level: two pairs per lane
@@ -3052,10 +3053,10 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
         const dim3 grid2((unsigned)gx2 * gy2 * gz2);
         if (fnt2)
             MGX_LAUNCH((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, true, 2>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx,
-                               sy, zb, ze, hx2, hy2, hz2, colour, zchunk, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
+                               sy, zb, ze, hx2, hy2, hz2, colour, zchunk, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax, zg0);
         else
             MGX_LAUNCH((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, false, 2>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx,
-                               sy, zb, ze, hx2, hy2, hz2, colour, zchunk, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
+                               sy, zb, ze, hx2, hy2, hz2, colour, zchunk, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax, zg0);
         return;
     }
     if (ctx->corr_low && sizeof(real) == 8) {  // EXPERIMENT: 8-wave workgroups (tiles of 8 rows), two to a CU
@@ -3072,10 +3073,10 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
         const dim3 gridl((unsigned)gxl * gyl * gzl);
         if (fntl)
             MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, 4, 2, true, 2>), gridl, dim3(64, 8, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zb,
-                               ze, hx2, hy2, hz2, colour, zchunk, gxl, gyl, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
+                               ze, hx2, hy2, hz2, colour, zchunk, gxl, gyl, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax, zg0);
         else
             MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, 4, 2, false, 2>), gridl, dim3(64, 8, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zb,
-                               ze, hx2, hy2, hz2, colour, zchunk, gxl, gyl, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax);
+                               ze, hx2, hy2, hz2, colour, zchunk, gxl, gyl, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax, zg0);
         return;
     }
     if (zchunk <= 0) {  // one resident round of 16-wave workgroups as in relax3d_xs_pass_lds
@@ -3093,10 +3094,10 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
     memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
     if (fnt)
         MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, 8, 2, true, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
-                           hx2, hy2, hz2, colour, zchunk, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax);
+                           hx2, hy2, hz2, colour, zchunk, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax, zg0);
     else
         MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, 8, 2, false, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
-                           hx2, hy2, hz2, colour, zchunk, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax);
+                           hx2, hy2, hz2, colour, zchunk, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax, zg0);
 }
 
 // v += Interpolate(coarse_v) on the interior, then `ncycles` >= 1 red-black sweeps (N3/MultiGrid3D.cpp:638-645), x-split
@@ -3170,7 +3171,7 @@ int relax3d_corr_colour_slab(mgx_ctx* ctx, real* v, const real* f, const int n[3
     const real hx2 = h[0] * h[0], hy2 = h[1] * h[1], hz2 = h[2] * h[2];
     const Geo<XSplit, real> gc(cn[0], cn[1]);
     corr_red_launch<real>(ctx, v, f, n[0], n[1], zbeg, zend, hx2, hy2, hz2, 0, coarse_v + gc.PL * (size_t)(fzoff / 2 - czoff), cn[0], cn[1],
-                          n[2] - fzoff, ckmax);
+                          n[2] - fzoff, ckmax, fzoff);
     MGX_LAUNCH_CHECK();
     return MGX_OK;
 }

@@ -823,7 +823,7 @@ class LocalGroup:
 def _dist_struct(ct):
     class Slab3D(C.Structure):
         _fields_ = [("d_v", C.c_void_p), ("d_f", C.c_void_p), ("sizeXYZ", C.c_int * 3), ("plan", SlabPlan), ("h_x", ct),
-                    ("h_y", ct), ("h_z", ct), ("x_a", ct), ("y_a", ct), ("z_a", ct)]
+                    ("h_y", ct), ("h_z", ct), ("x_a", ct), ("y_a", ct), ("z_a", ct), ("level", C.c_int)]
 
     class DistMultiGrid3D(C.Structure):
         _fields_ = [("slabs", C.POINTER(C.POINTER(Slab3D))), ("numDist", C.c_int), ("numGrids", C.c_int), ("maxGrids", C.c_int),
@@ -831,7 +831,9 @@ def _dist_struct(ct):
                     ("residual_mode", C.c_int), ("d_share", C.c_void_p), ("d_bplane", C.c_void_p), ("d_norm", C.c_void_p),
                     ("norm_count", C.c_int), ("inline_bytes", C.c_longlong), ("v_rim_zero", C.c_ubyte * 32),
                     ("use_graph", C.c_int), ("graph_exec", C.c_void_p), ("graph_key", C.c_longlong), ("graph_warm", C.c_int),
-                    ("pack_halos", C.c_int), ("d_stage", C.c_void_p), ("stage_half", C.c_size_t)]
+                    ("pack_halos", C.c_int), ("d_stage", C.c_void_p), ("stage_half", C.c_size_t),
+                    ("ca_min_planes", C.c_int), ("gv", C.c_byte * 32), ("gf", C.c_byte * 32), ("comm_pending", C.c_int),
+                    ("n_exchanges", C.c_longlong)]
 
     return Slab3D, DistMultiGrid3D
 
@@ -843,7 +845,7 @@ class DistMultiGrid3D(_MGBase):
     _prefix = "mgDistMultiGrid3D"
 
     def __init__(self, ctx, finestGridSizeXYZ, rng, dtype=np.float64, nlevels=0, residual_mode=REF_COMPAT, min_planes=4,
-                 inline_bytes=None, use_graph=False, pack_halos=None):
+                 inline_bytes=None, use_graph=False, pack_halos=None, ca_min_planes=None):
         self.ctx = ctx
         self.dtype = np.dtype(dtype)
         self._sfx, self._ct = _ct(dtype)
@@ -860,6 +862,13 @@ class DistMultiGrid3D(_MGBase):
         self._mg.contents.use_graph = int(bool(use_graph))  # opt-in: VCycle(0, ...) captured (RCCL calls included) and replayed
         if pack_halos is not None:  # None: the library default (0 = whole planes)
             self._mg.contents.pack_halos = int(bool(pack_halos))
+        if ca_min_planes is not None:  # None: the library default (16); 0: one exchange per colour pass on every level
+            self._mg.contents.ca_min_planes = int(ca_min_planes)
+
+    @property
+    def n_exchanges(self):
+        """halo exchanges + collectives this rank has enqueued since the hierarchy was created"""
+        return int(self._mg.contents.n_exchanges)
 
     @property
     def inline_bytes(self):

@@ -88,9 +88,10 @@ def test_plan_invariants():
                 for a, b in zip(plans, plans[1:]):
                     assert a.zhi == b.zlo            # contiguous ownership
                     assert b.zlo % 2 == 0            # owner of coarse k owns fine 2k, 2k+1
-                    assert b.glo == 2 and a.ghi == 1
+                    deep = (size - 1) // world >= 8  # MG_DEEP_MIN_PLANES: 6 ghost planes either side, else 2 below / 1 above
+                    assert (b.glo, a.ghi) == ((6, 6) if deep else (2, 1))
                 for p in plans:
-                    assert p.zoff == p.zlo - p.glo and p.zoff % 2 == 0
+                    assert p.zoff == p.zlo - p.glo and p.zoff % 2 == 0 and p.zoff >= 0 and p.zoff + p.nzl <= size
                     assert p.nzl == p.zhi - p.zlo + p.glo + p.ghi
                     assert 1 <= p.ubeg <= p.uend <= size - 1
                 size = (size - 1) // 2 + 1

@@ -24,7 +24,7 @@ DELAY_US = 300  # a colour pass of these grids takes 5-50 us: every transfer arr
 
 def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COMPAT, v0=None, f0=None, nlevels=0, fmg=0,
               delay_us=DELAY_US, drop_waits=False, extra=None, join_timeout=100, inline_bytes=0, v_levels=None, params=None,
-              pack_halos=None):
+              pack_halos=None, ca_min_planes=None, counts=None):
     """inline_bytes = 0: every level runs the OVERLAPPED schedule (comm stream, edge planes first) -- what these tests were
     written for; None: the library default (small levels exchange inline on the compute stream); a number: that threshold"""
     ctxs = [P.Context(0) for _ in range(nranks)]
@@ -41,7 +41,7 @@ def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COM
     def worker(r):
         try:
             mg = P.DistMultiGrid3D(ctxs[r], n3, rng, dtype, nlevels=nlevels, residual_mode=mode, min_planes=min_planes,
-                                   inline_bytes=inline_bytes, pack_halos=pack_halos)
+                                   inline_bytes=inline_bytes, pack_halos=pack_halos, ca_min_planes=ca_min_planes)
             info[r] = (mg.numDist, mg.numGrids)
             if f0 is not None:
                 mg.upload_f(0, f0)
@@ -52,7 +52,10 @@ def run_ranks(nranks, n3, rng, dtype, v1, v2, cycles, min_planes, mode=P.REF_COM
             if fmg:
                 mg.FullMultiGridVCycle(0, fmg, v1, v2)
             for _ in range(cycles):
+                before = mg.n_exchanges
                 mg.VCycle(0, v1, v2)
+                if counts is not None:
+                    counts.setdefault(r, []).append(mg.n_exchanges - before)  # exchanges + collectives of this cycle
             if extra is not None:
                 info[("extra", r)] = extra(mg)
             mg.download_v_into(0, full)
@@ -182,7 +185,9 @@ def test_dist_last_black_pass_inside_residual_restrict_on_slabs(nranks, v1, dtyp
     v0 = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
     f0 = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
     names = {}
-    got, info = run_ranks(nranks, n3, rg, dtype, v1, 2, 2, 16, v0=v0, f0=f0, params={"rr3d.black": 2},
+    # ca_min_planes = 0: this test is about the exchange-per-colour-pass schedule (slab_black_rr_); the communication-avoiding
+    # schedule has its own suite (tests/test_gpu_dist_ca.py)
+    got, info = run_ranks(nranks, n3, rg, dtype, v1, 2, 2, 16, v0=v0, f0=f0, params={"rr3d.black": 2}, ca_min_planes=0,
                           extra=lambda mg: names.setdefault(mg.rank, mg.ctx.last_rr_kernel()))
     assert all(names[r].startswith("relax_rr3d_xs_kernel") for r in range(nranks)), names
     want = O.cycle3d(n3, rg, mode=0, v1=v1, v2=2, reps=2, v=v0, f=f0, dtype=dtype)
