@@ -2,7 +2,8 @@
 """One-off fuzz of the z-slab driver (thread-ranks on one GPU over the asynchronous test transport, delay hook on) against
 the single-GPU hierarchy: random shapes, rank counts, agglomeration thresholds, sweep counts, modes, V-cycles and FMG.
 
-    python3 tests/checkers/fuzz_dist.py [cases] [seed]
+    python3 tests/checkers/fuzz_dist.py [cases] [seed] [zmin]
+zmin: the z size of every case is at least that (129 / 257: slabs thick enough for the communication-avoiding schedule)
 """
 import os
 import sys
@@ -22,6 +23,7 @@ PARAMS = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in filter(None, os.envi
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+zmin = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 bad = 0
 for c in range(cases):
     dtype = np.float64 if rng.random() < 0.6 else np.float32
@@ -29,6 +31,8 @@ for c in range(cases):
     mp = int(rng.choice([2, 4, 8, 16]))
     while True:  # the finest level must be distributable: an even number >= min_planes of planes per rank
         n = [int(rng.choice([9, 17, 33, 65, 129, 257])) for _ in range(3)]
+        if n[2] < zmin:
+            n[2] = int(rng.choice([s for s in (129, 257) if s >= zmin]))
         if np.prod(n) <= 6e6 and (n[2] - 1) % nr == 0 and (n[2] - 1) // nr >= max(2, mp) and ((n[2] - 1) // nr) % 2 == 0:
             break
     box = [0.0, float(rng.choice([1.0, 2.0, 1.5])), 0.0, float(rng.choice([1.0, 3.0])), 0.0, float(rng.choice([1.0, 0.5]))]

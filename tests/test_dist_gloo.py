@@ -76,6 +76,48 @@ def test_slab_fmg_world2_matches_single_domain(tmp_path, n, min_planes, mode):
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
 
 
+@pytest.mark.parametrize("n,v1,v2,cycles", [(65, 2, 2, 2), (65, 1, 3, 1), (33, 2, 1, 2), (65, 4, 2, 1)])
+def test_ca_schedule_world2_matches_single_domain(tmp_path, n, v1, v2, cycles):
+    """the communication-avoiding schedule (slabs of >= 16 planes: 6 ghost planes, one exchange of v per Relax call, the first
+    ghost planes relaxed redundantly, edges first / interior behind the exchange) restated with the oracle's operators
+    (tests/dist_gloo_ca_worker.py): every half-plane carries the number of colour passes it has seen and every pass asserts that
+    it reads exactly the version the serial algorithm reads.  65^3 on 2 ranks: level 0 (32 planes per rank) splits into edges
+    and interior, level 1 (16) does not; 33^3: one level; V(4,2): eight passes = two chunks with an exchange in between."""
+    world = 2
+    out = str(tmp_path / "ca%d.npy")
+    port = _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gloo_ca_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker] + [str(a) for a in (r, world, port, n, v1, v2, cycles, out)]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    got = np.concatenate([np.load(out % r) for r in range(world)], axis=0)
+    want = O.cycle3d([n] * 3, R3, mode=0, v1=v1, v2=v2, reps=cycles, dtype=np.float64)
+    assert got.shape == want.shape and not np.isnan(got).any()
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    counts = [np.load((out % r) + ".count.npy").tolist() for r in range(world)]
+    assert counts[0] == counts[1]
+    if (v1, v2) == (2, 2) and n == 65:  # level 0: v behind pre- and post-smoothing; level 1: f, v, v; the all-gather
+        assert max(counts[0]) <= 6, counts
+
+
+def test_ca_schedule_emulation_notices_a_ghost_plane_trusted_too_long(tmp_path):
+    """the emulation's version check is what proves a schedule right: with every pass reaching one ghost plane further than its
+    inputs allow (CA_EMU_FAULT=1) a rank must fail"""
+    world, port = 2, _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gloo_ca_worker.py")
+    env = dict(os.environ, CA_EMU_FAULT="1")
+    procs = [subprocess.Popen([sys.executable, worker] + [str(a) for a in (r, world, port, 65, 2, 2, 1, str(tmp_path / "f%d.npy"))], env=env,
+                              stderr=subprocess.DEVNULL) for r in range(world)]
+    codes = []
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=120))
+        except subprocess.TimeoutExpired:  # the peer of a failed rank waits for a message that never comes
+            p.kill()
+            codes.append(-9)
+    assert any(c not in (0, -9) for c in codes), codes
+
+
 def test_plan_invariants():
     for world in (1, 2, 4, 8):
         for n in (33, 65, 513, 1025):
