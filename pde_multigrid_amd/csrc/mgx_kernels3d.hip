@@ -2235,6 +2235,19 @@ static bool relax3d_lds_shape_known(int shape) {
 
 // LDS-exchange smoother: "relax3d.lds" = 1000 + 100*WX + 10*WY + R picks the workgroup shape (+ 2000: non-temporal f).
 // Returns false when the level is too small for the shape (the caller falls back to relax3d_xs_kernel).
+// the shortest run of planes the automatic choice hands to the pipelined kernel.  Its launch has a floor (one workgroup per tile
+// column filling and draining its pipeline: ~20 us at 1025-point rows, 17 us at 513, 11.5 us at 257) under which
+// relax3d_xs_kernel's many small workgroups win; measured per plane size and run length with tools/slab_pass_time.py
+// (profiles/r04_slab_pass_time.txt; fp64): 1025^2: pipelined from 9 planes on (21.9 against 26.9 us), 513^2: from ~24 (11 planes:
+// 17.2 against 10.4 us, 32: 20.5 against 23.4), 257^2: from ~64 (38 planes: 12.3 against 9.4 us).  Whole levels have hundreds
+// of planes; the short runs are the edge passes and thin slabs of the multi-GPU schedule.
+template <class real>
+static int pipe_min_planes(int sx) {
+    const int M = (sx + 1) / 2;
+    if (sizeof(real) == 4) return 8;
+    return M - 1 >= 512 ? 8 : (M - 1 >= 256 ? 24 : 64);
+}
+
 template <class real>
 static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zbeg, int zend, real hx2, real hy2,
                                 real hz2, int colour) {
@@ -2267,7 +2280,7 @@ static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, in
         // workgroups -- about one 16-wave workgroup per CU, each streaming a long run of planes (fp32 moves half the
         // bytes per wave and wants 8 x as many, shorter runs); below 257^2 rows, or for runs of a few planes (the
         // edge planes of a z-slab), relax3d_xs_kernel is faster.
-        if (M - 1 < 128 || sy - 2 < 64 || zend - zbeg < 8) return false;
+        if (M - 1 < 128 || sy - 2 < 64 || zend - zbeg < pipe_min_planes<real>(sx)) return false;
         // f is read exactly once per pass: load it non-temporally when the pass is too large to stay in the 256 MiB
         // Infinity Cache anyway (+1.5 % at 513^3 and 1025^3); a cache-resident level (257^3) is 5 % faster without
         code = (size_t)sx * sy * (size_t)(zend - zbeg) * sizeof(real) > ((size_t)256 << 20) ? 3282 : 1282;
@@ -2370,7 +2383,8 @@ static void relax3d_xs_pass(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
 template <class real>
 static bool relax3d_xs_pass2(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, int zb1, int ze1, int zb2, int ze2, real hx2, real hy2,
                              real hz2, int colour) {
-    if (!ctx->slab_edges_merged || ze1 <= zb1 || ze2 <= zb2 || ze1 - zb1 >= 8 || ze2 - zb2 >= 8 || sx < 3 || sy < 3) return false;
+    const int pmin = ctx->relax_lds == 0 ? (1 << 30) : pipe_min_planes<real>(sx);  // runs the pipelined kernel would take: two passes
+    if (!ctx->slab_edges_merged || ze1 <= zb1 || ze2 <= zb2 || ze1 - zb1 >= pmin || ze2 - zb2 >= pmin || sx < 3 || sy < 3) return false;
     constexpr int TYW = 4, R = 4;
     const int zchunk = 1;
     const int M = (sx + 1) / 2;

@@ -59,7 +59,10 @@ def test_ca_wide_rows_fused_forms(nranks, n3, dtype):
     assert bits_equal(got, want)
     if dtype == np.float64:  # the fused way down is the fp64 kernel
         assert all(names[r][0].startswith("relax_rr3d_xs_kernel") for r in range(nranks)), names
-    assert all(names[r][1].startswith("relax3d_xs_pipe") for r in range(nranks)), names
+    if (n3[2] - 1) // nranks >= 96:  # thinner slabs correct the black points in place with one launch and run plain passes
+        assert all(names[r][1].startswith("relax3d_xs_pipe") for r in range(nranks)), names
+    else:
+        assert all(names[r][1] == "" for r in range(nranks)), names
 
 
 @pytest.mark.timeout(300)

@@ -19,6 +19,8 @@ nranks = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 one_gpu_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 only_rank = int(sys.argv[4]) if len(sys.argv) > 4 else -1
 R3 = [0, 1, 0, 1, 0, 1]
+MIN_PLANES = int(os.environ.get("MGX_REHEARSE_MIN_PLANES", "32"))  # bench.py's --min-planes default
+CA = os.environ.get("MGX_REHEARSE_CA")  # ca_min_planes of the hierarchy (unset: the library default)
 
 
 def timed(ctx, mg, steps=10):
@@ -51,15 +53,18 @@ for inline_bytes, label in ((modes[0], modes[3]) if only_rank >= 0 else modes):
         for kv in filter(None, os.environ.get("MGX_PARAMS", "").split(",")):  # e.g. MGX_PARAMS=slab.edges_merged=0
             ctx.set_param(kv.split("=")[0], int(kv.split("=")[1]))
         ctx.comm_init_rehearsal(P.Context.unique_id(), vr, nranks)
-        mg = P.DistMultiGrid3D(ctx, [n] * 3, R3, np.float64, min_planes=32, inline_bytes=None if inline_bytes == -1 else inline_bytes,
-                               use_graph=inline_bytes == -1)
+        mg = P.DistMultiGrid3D(ctx, [n] * 3, R3, np.float64, min_planes=MIN_PLANES, inline_bytes=None if inline_bytes == -1 else inline_bytes,
+                               use_graph=inline_bytes == -1, ca_min_planes=None if CA is None else int(CA))
+        ex0 = mg.n_exchanges
+        mg.VCycle(0, 2, 2)
+        exch = mg.n_exchanges - ex0
         ms = timed(ctx, mg)
         nd = mg.numDist
         mg.close()
         ctx.close()
         rows.append((label, vr, ms))
-        print("%-40s rank %d of %d (%d distributed levels): %.3f ms per cycle -> speed-up bound %.2f x of %d" % (
-            label, vr, nranks, nd, ms, one_gpu_ms / ms, nranks), flush=True)
+        print("%-40s rank %d of %d (%d distributed levels, %d exchanges per cycle): %.3f ms per cycle -> speed-up bound %.2f x of %d" % (
+            label, vr, nranks, nd, exch, ms, one_gpu_ms / ms, nranks), flush=True)
 worst = {}
 for label, vr, ms in rows:
     worst[label] = max(worst.get(label, 0.0), ms)
