@@ -71,6 +71,7 @@ struct mgx_ctx {
     void* rehearse_buf = nullptr;  // its scratch: the partner buffer of a send / receive that has none on this rank
     size_t rehearse_bytes = 0;
     int num_cus = 256;
+    int pipe_unroll = 7;              // "relax3d.unroll": bit mask, see mgx_ctx_set_param
     int corr_low = 0;                 // "relax3d.corr_low": the fp64 correcting red pass in 8-wave workgroups, two to a CU
     int slab_edges_merged = 1;        // "slab.edges_merged": mgx3dxs_relax_colour_slab2_* makes one launch of its two plane ranges
     int resident_tile = 0;            // "relax3d.resident_tile": 0 = by level, 8 = tiles of 8 x 8 lines always (tests, timing)

@@ -37,6 +37,8 @@
 //                             (large levels) / streaming register window / LDS rolling window (Natural)
 //   interpolate3d_xs_kernel   Interpolate (+ApplyCorrection, optionally one colour only), XSplit
 //   relayout3d_kernel         Natural <-> XSplit (upload / download of the hierarchy)
+#include <type_traits>
+
 #include "mgx_internal.hpp"
 #include "mgx_kernels3d.hpp"
 #include "mgx_sync.hpp"
@@ -425,7 +427,7 @@ __device__ __forceinline__ real interp_xs_at(const real* __restrict__ coarse, in
                                      [&](int dx, int dy, int dz) { return c[XSplit::pos(gx + dx, CH) + dy * CP + (size_t)dz * CPL]; });
 }
 
-template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0>
+template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0, int UNR = 0>
 __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whatever the shape: 8-wave workgroups run two to a CU
     relax3d_xs_pipe_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                            int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
@@ -708,6 +710,55 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
     publish(z0 & 1, cc);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (UNR != 0) {
+        // The same schedule with the loop unrolled four times and every register role fixed per step: the planes of the column
+        // live in c[4][R] (step k: c[k & 3] = plane z - 1, c[(k + 1) & 3] = z, c[(k + 2) & 3] = z + 1, c[(k + 3) & 3] = the one on
+        // its way), f / rim / edge rows / results in pairs of sets by step parity, and the row parity q is a literal: the 13 register
+        // copies and ~25 parity selects of a rolled step are gone (the passes that are bound by instruction issue -- the correcting
+        // pass, fp32 -- spend a fifth of their vector instructions on them).  Same loads, same stores, same arithmetic.
+        // UNR - 1 = the row parity q of the run's first plane: the host launches the instantiation that fits (every run of a launch
+        // starts with the same parity: runs are an even number of planes long, and y0 is odd)
+        static_assert(R % 2 == 0, "the unrolled loop takes y0 to be odd");
+        real c[4][R], fb[2][R], xb[2][R], ob[2][R], nb2[2], sb2[2];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            c[0][r] = cp[r]; c[1][r] = cc[r]; c[2][r] = cu[r]; c[3][r] = 0;
+            fb[0][r] = fc[r]; fb[1][r] = 0;
+            xb[0][r] = xc[r]; xb[1][r] = 0;
+            ob[0][r] = ob[1][r] = 0;
+        }
+        nb2[0] = Nc; nb2[1] = 0;
+        sb2[0] = Sc; sb2[1] = 0;
+        unsigned kgb[WX + 1];  // CORR: byte offsets of the coarse entries this thread stages
+#pragma unroll
+        for (int a = 0; a <= WX; a++) kgb[a] = (unsigned)kg[a] * (unsigned)sizeof(real);
+        const unsigned jb = (unsigned)j * (unsigned)sizeof(real);  // the lane's byte offset inside a half-row; the rim lanes': the pair right / left
+        const unsigned jbR = (unsigned)(j + (rimR ? 1 : 0)) * (unsigned)sizeof(real), jbL = (unsigned)(j + (rimL ? (j ? -1 : M - 1) : 0)) * (unsigned)sizeof(real);
+        {
+            int z = z0;
+            for (;;) {
+#define MGX_K 0
+#include "mgx_pipe_step.inc"
+#undef MGX_K
+                if (++z >= z1) break;
+#define MGX_K 1
+#include "mgx_pipe_step.inc"
+#undef MGX_K
+                if (++z >= z1) break;
+#define MGX_K 2
+#include "mgx_pipe_step.inc"
+#undef MGX_K
+                if (++z >= z1) break;
+#define MGX_K 3
+#include "mgx_pipe_step.inc"
+#undef MGX_K
+                if (++z >= z1) break;
+            }
+        }
+        const int kl = (z1 - z0 - 1) & 3;  // the last step: its results sit in ob[kl & 1], its row parity is (UNR - 1) ^ (kl & 1)
+        if (kl & 1) store_plane(-1, (UNR - 1) ^ 1, ob[1]);
+        else store_plane(-1, UNR - 1, ob[0]);
+    } else {
     for (int z = z0; z < z1; z++) {
         const bool more = z + 1 < z1;
         // a wave that has passed the barrier issues its stores and next loads at raised priority: requests leave the CU
@@ -826,6 +877,7 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
         q ^= 1;
     }
     store_plane(-1, q ^ 1, op);  // the last plane
+    }
 #undef MGX_LOAD_RIM
 #undef MGX_K_REQUEST
 #undef MGX_K_STORE
@@ -842,15 +894,11 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
 // loads one plane ahead, stores one plane behind, one barrier per plane), same per-point expression.  Of the two x
 // neighbours of an updated point one is the lane's own other-colour entry, the other one is -- depending on the element --
 // the lane's other element or the neighbouring lane's (wave shuffle; wave edge: LDS; tile edge: memory).
-template <class real>
-struct Vec2T {
-    typedef real type __attribute__((ext_vector_type(2)));
-};
 
 // VAR = 2: the correcting red pass of relax3d_xs_pipe_kernel (the black values read through v + Interpolate(coarse), coarse
 // planes staged in LDS, the set P corrected in place beforehand) for two pairs per lane: the staged tile is 128 WX + 2 coarse
 // columns wide, a lane interpolates for both of its pairs.
-template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0>
+template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0, int UNR = 0>
 __global__ void __launch_bounds__(64 * WX * WY)
     relax3d_xs_pipe_v2_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                               int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
@@ -1063,6 +1111,52 @@ __global__ void __launch_bounds__(64 * WX * WY)
     publish(z0 & 1, cc);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (UNR != 0) {
+        // the step loop unrolled four times with fixed register roles, literal row parity, buffer-descriptor addressing and the two
+        // points of a row as one vector expression: see relax3d_xs_pipe_kernel and mgx_pipe2_step.inc.  UNR - 1 = the row parity of
+        // the run's first plane (runs are an even number of planes long, y0 is odd).
+        static_assert(R % 2 == 0, "the unrolled loop takes y0 to be odd");
+        vec2 c[4][R], fb[2][R], ob[2][R], nb2[2], sb2[2];
+        real xb[2][R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            c[0][r] = cp[r]; c[1][r] = cc[r]; c[2][r] = cu[r]; c[3][r] = vec2{0, 0};
+            fb[0][r] = fc[r]; fb[1][r] = vec2{0, 0};
+            xb[0][r] = xc[r]; xb[1][r] = 0;
+            ob[0][r] = ob[1][r] = vec2{0, 0};
+        }
+        nb2[0] = Nc; nb2[1] = vec2{0, 0};
+        sb2[0] = Sc; sb2[1] = vec2{0, 0};
+        unsigned kgb[NK + 1];
+#pragma unroll
+        for (int a = 0; a <= NK; a++) kgb[a] = (unsigned)kg[a] * (unsigned)sizeof(real);
+        const unsigned jb = (unsigned)j0 * (unsigned)sizeof(real);  // the lane's byte offset inside a half-row; the rim lanes': the entry right / left
+        const unsigned jbR = (unsigned)(j0 + (rimR ? 2 : 0)) * (unsigned)sizeof(real), jbL = (unsigned)(j0 + (rimL ? (j0 ? -1 : M - 1) : 0)) * (unsigned)sizeof(real);
+        {
+            int z = z0;
+            for (;;) {
+#define MGX_K 0
+#include "mgx_pipe2_step.inc"
+#undef MGX_K
+                if (++z >= z1) break;
+#define MGX_K 1
+#include "mgx_pipe2_step.inc"
+#undef MGX_K
+                if (++z >= z1) break;
+#define MGX_K 2
+#include "mgx_pipe2_step.inc"
+#undef MGX_K
+                if (++z >= z1) break;
+#define MGX_K 3
+#include "mgx_pipe2_step.inc"
+#undef MGX_K
+                if (++z >= z1) break;
+            }
+        }
+        const int kl = (z1 - z0 - 1) & 3;  // the last step: its results sit in ob[kl & 1], its row parity is (UNR - 1) ^ (kl & 1)
+        if (kl & 1) store_plane(-1, (UNR - 1) ^ 1, ob[1]);
+        else store_plane(-1, UNR - 1, ob[0]);
+    } else {
     for (int z = z0; z < z1; z++) {
         const bool more = z + 1 < z1;
         if (z > z0) store_plane(-1, q ^ 1, op);
@@ -1163,6 +1257,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
         q ^= 1;
     }
     store_plane(-1, q ^ 1, op);
+    }
 #undef MGX_LOAD_RIM2
 #undef MGX_LD2
 #undef MGX_K2_REQUEST
@@ -2205,6 +2300,21 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
     const dim3 grid((unsigned)gx * gy * gz), block(64, WX * WY, 1);
     const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
     note_relax_kernel<real>(ctx, kind ? "relax3d_xs_pipe_kernel" : "relax3d_xs_lds_kernel", WX, WY, R, kind == 2 && R == 2 && WX * WY == 16);
+    // the shapes the automatic choice takes (2 x 8 and 2 x 4 waves of 2 rows): the step loop unrolled four times (see the kernel); the
+    // launch hands every run an even number of planes so that all runs start with the row parity the instantiation is compiled for
+    if constexpr (R == 2 && WX == 2 && (WY == 8 || WY == 4)) {
+        if (kind >= 1 && (ctx->pipe_unroll & 2) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8))) {
+            const int zce = zchunk + (zchunk & 1), q0 = (colour + 1 + zbeg) & 1;
+            const dim3 gride((unsigned)gx * gy * ceil_div(zend - zbeg, zce));
+#define MGX_PU(F, U)                                                                                                                    \
+    MGX_LAUNCH((relax3d_xs_pipe_kernel<real, WX, WY, 2, F, 0, U>), gride, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, \
+               hy2, hz2, colour, zce, gx, gy, xcd)
+            if (kind == 2 && WY == 8) { if (q0) MGX_PU(true, 2); else MGX_PU(true, 1); }
+            else { if (q0) MGX_PU(false, 2); else MGX_PU(false, 1); }
+#undef MGX_PU
+            return;
+        }
+    }
     if (kind == 2 && R == 2 && WX * WY == 16)  // f is read once per pass: non-temporal loads
         MGX_LAUNCH((relax3d_xs_pipe_kernel<real, WX, WY, (R == 2 && WX * WY == 16 ? R : 2), true>), grid, block, 0,
                            ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx, gy, xcd);
@@ -2266,6 +2376,17 @@ static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, in
         const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
         const dim3 grid2((unsigned)gx2 * gy2 * gz2);
         note_relax_kernel<real>(ctx, "relax3d_xs_pipe_v2_kernel", 2, 8, 2, fnt);
+        if (ctx->pipe_unroll & 4) {  // the step loop unrolled four times (runs of an even number of planes, entry parity q0)
+            const int zce = zchunk + (zchunk & 1), q0 = (colour + 1 + zbeg) & 1;
+            const dim3 gride((unsigned)gx2 * gy2 * ceil_div(zend - zbeg, zce));
+#define MGX_PU2(F, U)                                                                                                                  \
+    MGX_LAUNCH((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, F, 0, U>), gride, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zbeg, \
+               zend, hx2, hy2, hz2, colour, zce, gx2, gy2, xcd)
+            if (fnt) { if (q0) MGX_PU2(true, 2); else MGX_PU2(true, 1); }
+            else { if (q0) MGX_PU2(false, 2); else MGX_PU2(false, 1); }
+#undef MGX_PU2
+            return true;
+        }
         if (fnt)
             MGX_LAUNCH((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, true>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy,
                                zbeg, zend, hx2, hy2, hz2, colour, zchunk, gx2, gy2, xcd);
@@ -2341,9 +2462,19 @@ static bool relax3d_xs_first_sweep_zero(mgx_ctx* ctx, real* v, const real* f, in
 #define MGX_Z1(WYY, F)                                                                                                           \
     MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, WYY, 2, F, 3>), grid, dim3(64, 2 * WYY, 1), 0, ctx->compute, f, v, f, sx, sy, zbeg, zend, \
                        hx2, hy2, hz2, 1, zchunk, gx, gy, xcd, (const real*)nullptr, 0, 0, sz, 0)
-    if (low) MGX_Z1(4, false);
+#define MGX_Z1U(WYY, F, U)                                                                                                         \
+    MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, WYY, 2, F, 3, U>), gride, dim3(64, 2 * WYY, 1), 0, ctx->compute, f, v, f, sx, sy, zbeg, zend, \
+                       hx2, hy2, hz2, 1, zce, gx, gy, xcd, (const real*)nullptr, 0, 0, sz, 0)
+    if ((ctx->pipe_unroll & 2) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8))) {  // the step loop unrolled four times: runs of an even number of planes, entry parity (colour 1 + 1 + zbeg) & 1
+        const int zce = zchunk + (zchunk & 1), q0 = (1 + 1 + zbeg) & 1;
+        const dim3 gride((unsigned)gx * gy * ceil_div(zend - zbeg, zce));
+        if (low) { if (q0) MGX_Z1U(4, false, 2); else MGX_Z1U(4, false, 1); }
+        else if (fnt) { if (q0) MGX_Z1U(8, true, 2); else MGX_Z1U(8, true, 1); }
+        else { if (q0) MGX_Z1U(8, false, 2); else MGX_Z1U(8, false, 1); }
+    } else if (low) MGX_Z1(4, false);
     else if (fnt) MGX_Z1(8, true);
     else MGX_Z1(8, false);
+#undef MGX_Z1U
 #undef MGX_Z1
     return true;
 }
@@ -3065,6 +3196,17 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
                  fnt2 ? "true" : "false");
         memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
         const dim3 grid2((unsigned)gx2 * gy2 * gz2);
+        if (ctx->pipe_unroll & 4) {
+            const int zce = zchunk + (zchunk & 1), q0 = (colour + 1 + zb) & 1;
+            const dim3 gride((unsigned)gx2 * gy2 * ceil_div(ze - zb, zce));
+#define MGX_CU2(F, U)                                                                                                                   \
+    MGX_LAUNCH((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, F, 2, U>), gride, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze, \
+               hx2, hy2, hz2, colour, zce, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax, zg0)
+            if (fnt2) { if (q0) MGX_CU2(true, 2); else MGX_CU2(true, 1); }
+            else { if (q0) MGX_CU2(false, 2); else MGX_CU2(false, 1); }
+#undef MGX_CU2
+            return;
+        }
         if (fnt2)
             MGX_LAUNCH((relax3d_xs_pipe_v2_kernel<real, 2, 8, 2, true, 2>), grid2, dim3(64, 16, 1), 0, ctx->compute, (const real*)v, v, f, sx,
                                sy, zb, ze, hx2, hy2, hz2, colour, zchunk, gx2, gy2, ctx->relax_xcd == 1 ? 1 : 0, coarse_sh, cx, cy, szl, ckmax, zg0);
@@ -3106,6 +3248,19 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
     snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,2,8,2,%s,2>", sizeof(real) == 8 ? "double" : "float",
              fnt ? "true" : "false");
     memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
+    if ((ctx->pipe_unroll & 1) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8))) {
+        // the step loop unrolled four times, register roles and row parity fixed per step: runs of an even number of planes, so
+        // that every run starts with the row parity q0 the instantiation is compiled for
+        const int zce = zchunk + (zchunk & 1), q0 = (colour + 1 + zb) & 1;
+        const dim3 gride((unsigned)gx * gy * ceil_div(ze - zb, zce));
+#define MGX_CU(F, U)                                                                                                                     \
+    MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, 8, 2, F, 2, U>), gride, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze, hx2, hy2, \
+               hz2, colour, zce, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax, zg0)
+        if (fnt) { if (q0) MGX_CU(true, 2); else MGX_CU(true, 1); }
+        else { if (q0) MGX_CU(false, 2); else MGX_CU(false, 1); }
+#undef MGX_CU
+        return;
+    }
     if (fnt)
         MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, 8, 2, true, 2>), grid, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zb, ze,
                            hx2, hy2, hz2, colour, zchunk, gx, gy, xcd, coarse_sh, cx, cy, szl, ckmax, zg0);
@@ -3619,6 +3774,13 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "relax3d.fused_lead")) {
         MGX_REQUIRE(value == 0 || (value >= 5 && value <= 7), MGX_ERR_INVALID, "relax3d.fused_lead (planes the red stage runs ahead) must be 0 (default), 5, 6 or 7");
         ctx->sweep_lead = value;
+    } else if (!strcmp(name, "relax3d.unroll")) {
+        // the pipelined smoother's step loop unrolled four times with fixed register roles (same loads, stores, arithmetic; measured:
+        // tools/level_timing.py).  Bit 0: the correcting red pass, bit 1: the plain pass and the from-zero sweep (2 x 8 / 2 x 4 waves of
+        // 2 rows), bit 2: the fp32 two-pair kernels; bits 0 and 1 apply to fp64 only (the fp32 one-pair kernels of the 257^3 level run
+        // short runs in many workgroups and lose 10 % unrolled) unless bit 3 is set too (tests).  Default 7.
+        MGX_REQUIRE(value >= 0 && value <= 15, MGX_ERR_INVALID, "set_param: relax3d.unroll = %d not in [0, 15]", value);
+        ctx->pipe_unroll = value;
     } else if (!strcmp(name, "relax3d.zchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "relax3d.zchunk must be >= 0 (0 = automatic)");
         ctx->relax_zchunk = value;

@@ -45,6 +45,12 @@ struct Geo {
     __host__ __device__ __forceinline__ int pos(int x) const { return L::pos(x, H); }
 };
 
+// two consecutive elements of `real` as one vector value
+template <class real>
+struct Vec2T {
+    typedef real type __attribute__((ext_vector_type(2)));
+};
+
 // MultiGrid3D::Relax per-point update.                      N3/MultiGrid3D.cpp:532 (=:561)
 //   v = (O*(hy2*hz2)+E*(hy2*hz2) + N*(hx2*hz2)+S*(hx2*hz2) + D*(hx2*hy2)+U*(hx2*hy2)
 //        - f*hx2*hy2*hz2) / (2*(hy2*hz2 + hx2*hz2 + hx2*hy2))
@@ -79,6 +85,22 @@ __device__ __forceinline__ real relax3d_point_rd(real O, real E, real N, real S,
         return q;
     } else {
         return relax3d_point<real>(O, E, N, S, D, U, f, hx2, hy2, hz2);
+    }
+}
+
+// relax3d_point_rd for the two points a lane of relax3d_xs_pipe_v2_kernel updates in a row, as ONE element-wise vector expression
+// (fp32: v_pk_mul_f32 / v_pk_add_f32 -- every element goes through the operations of the scalar form in the same order: same bits).
+template <class real, class vec2>
+__device__ __forceinline__ vec2 relax3d_point_rd2(vec2 O, vec2 E, vec2 N, vec2 S, vec2 D, vec2 U, vec2 f, real hx2, real hy2, real hz2, double rd) {
+    const vec2 num = O * (hy2 * hz2) + E * (hy2 * hz2) + N * (hx2 * hz2) + S * (hx2 * hz2) + D * (hx2 * hy2) + U * (hx2 * hy2) - f * hx2 * hy2 * hz2;
+    const real den = 2 * (hy2 * hz2 + hx2 * hz2 + hx2 * hy2);
+    if constexpr (sizeof(real) == 4) {
+        vec2 q = {(real)((double)num.x * rd), (real)((double)num.y * rd)};
+        // a result below FLT_MIN (zero included) in either element: both are divided for real (one branch per row instead of one per point)
+        if (__builtin_expect(!(__builtin_fabsf(q.x) >= 1.17549435e-38f) || !(__builtin_fabsf(q.y) >= 1.17549435e-38f), 0)) q = vec2{num.x / den, num.y / den};
+        return q;
+    } else {
+        return vec2{num.x / den, num.y / den};
     }
 }
 
@@ -144,6 +166,59 @@ __device__ __forceinline__ real interpolate3d_point(int ox, int oy, int oz, Get 
 }
 
 // ------------------------------------------------------------------ device helpers shared by the kernel files
+// Loads and stores through buffer descriptors: the address is descriptor base (the plane, SGPRs) + a uniform offset (row and
+// plane, one SGPR) + the lane's 32-bit offset inside the row -- no 64-bit address arithmetic in vector registers, which this
+// kernel has none to spare.  The descriptor covers `planes` planes from its base; stride 0 (raw), the gfx950 format word.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <class real>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const real* base, int plane_elems, int planes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((unsigned)plane_elems * (unsigned)planes * (unsigned)sizeof(real)), 0x00020000);
+}
+template <class real>
+__device__ __forceinline__ real buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff_elems) {
+    if constexpr (sizeof(real) == 8) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, (unsigned)soff_elems * 8u, 0);
+        return __builtin_bit_cast(double, t);
+    } else {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, (unsigned)soff_elems * 4u, 0));
+    }
+}
+template <class real>
+__device__ __forceinline__ void buf_store_nt(real x, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff_elems) {
+    if constexpr (sizeof(real) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, (unsigned)soff_elems * 8u, 2);
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, (unsigned)soff_elems * 4u, 2);
+}
+// two consecutive elements (the two x-pairs of a lane of relax3d_xs_pipe_v2_kernel) as one 8- / 16-byte access
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <class real, int AUX>
+__device__ __forceinline__ typename Vec2T<real>::type buf_load2_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff_elems) {
+    typedef typename Vec2T<real>::type vec2;
+    if constexpr (sizeof(real) == 8) return __builtin_bit_cast(vec2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, (unsigned)soff_elems * 8u, AUX));
+    else return __builtin_bit_cast(vec2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, (unsigned)soff_elems * 4u, AUX));
+}
+template <class real>
+__device__ __forceinline__ typename Vec2T<real>::type buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff_elems) {
+    return buf_load2_aux<real, 0>(r, voff, soff_elems);
+}
+template <class real>
+__device__ __forceinline__ typename Vec2T<real>::type buf_load2_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff_elems) {
+    return buf_load2_aux<real, 2>(r, voff, soff_elems);
+}
+template <class real>
+__device__ __forceinline__ void buf_store2_nt(typename Vec2T<real>::type x, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff_elems) {
+    if constexpr (sizeof(real) == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), r, voff, (unsigned)soff_elems * 8u, 2);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, (unsigned)soff_elems * 4u, 2);
+}
+template <class real>
+__device__ __forceinline__ real buf_load_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff_elems) {  // read once: non-temporal
+    if constexpr (sizeof(real) == 8) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, (unsigned)soff_elems * 8u, 2);
+        return __builtin_bit_cast(double, t);
+    } else {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, (unsigned)soff_elems * 4u, 2));
+    }
+}
+
 // block -> tile of a 1-D launch over gx x gy x gz tiles (x fastest).  xcd_mode 1: consecutive blocks go to the eight XCDs
 // in turn, so every XCD is given one contiguous run of the tile order -- workgroups whose tiles share rows or cache lines
 // then share an L2 (see relax3d_xs_kernel); xcd_mode 0: plain order.

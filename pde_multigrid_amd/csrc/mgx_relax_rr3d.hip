@@ -33,28 +33,7 @@
 
 namespace mgx {
 
-// Loads and stores through buffer descriptors: the address is descriptor base (the plane, SGPRs) + a uniform offset (row and
-// plane, one SGPR) + the lane's 32-bit offset inside the row -- no 64-bit address arithmetic in vector registers, which this
-// kernel has none to spare.  The descriptor covers `planes` planes from its base; stride 0 (raw), the gfx950 format word.
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-template <class real>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const real* base, int plane_elems, int planes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((unsigned)plane_elems * (unsigned)planes * (unsigned)sizeof(real)), 0x00020000);
-}
-template <class real>
-__device__ __forceinline__ real buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff_elems) {
-    if constexpr (sizeof(real) == 8) {
-        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, (unsigned)soff_elems * 8u, 0);
-        return __builtin_bit_cast(double, t);
-    } else {
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, (unsigned)soff_elems * 4u, 0));
-    }
-}
-template <class real>
-__device__ __forceinline__ void buf_store_nt(real x, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff_elems) {
-    if constexpr (sizeof(real) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, (unsigned)soff_elems * 8u, 2);
-    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, (unsigned)soff_elems * 4u, 2);
-}
+// (plane_rsrc / buf_load / buf_store_nt: loads and stores through buffer descriptors, mgx_kernels3d.hpp)
 
 // DBG (diagnostic builds only): `abl` switches parts of an iteration off for timing (WRONG results): 1 no loads, 2 no stores of
 // v, 4 no relax arithmetic, 8 no residual arithmetic, 16 no barrier, 32 no sub-sums / coarse rows.
