@@ -716,14 +716,20 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
         // its way), f / rim / edge rows / results in pairs of sets by step parity, and the row parity q is a literal: the 13 register
         // copies and ~25 parity selects of a rolled step are gone (the passes that are bound by instruction issue -- the correcting
         // pass, fp32 -- spend a fifth of their vector instructions on them).  Same loads, same stores, same arithmetic.
-        // UNR - 1 = the row parity q of the run's first plane: the host launches the instantiation that fits (every run of a launch
-        // starts with the same parity: runs are an even number of planes long, and y0 is odd)
+        // (UNR - 1) & 1 = the row parity q of the run's first plane: the host launches the instantiation that fits (every run of a
+        // launch starts with the same parity: runs are an even number of planes long, and y0 is odd).  UNR >= 3: DEPTH 2 -- the column
+        // and f are requested two steps ahead (mgx_pipe_step.inc), six steps per loop trip.
         static_assert(R % 2 == 0, "the unrolled loop takes y0 to be odd");
-        real c[4][R], fb[2][R], xb[2][R], ob[2][R], nb2[2], sb2[2];
+        constexpr int DEPTH = UNR >= 3 ? 2 : 1, Q0 = (UNR - 1) & 1, CR = DEPTH == 2 ? 6 : 4, FR = DEPTH + 1;
+        real c[CR][R], fb[FR][R], xb[2][R], ob[2][R], nb2[2], sb2[2];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            c[0][r] = cp[r]; c[1][r] = cc[r]; c[2][r] = cu[r]; c[3][r] = 0;
-            fb[0][r] = fc[r]; fb[1][r] = 0;
+#pragma unroll
+            for (int k = 3; k < CR; k++) c[k][r] = 0;
+            c[0][r] = cp[r]; c[1][r] = cc[r]; c[2][r] = cu[r];
+#pragma unroll
+            for (int k = 1; k < FR; k++) fb[k][r] = 0;
+            fb[0][r] = fc[r];
             xb[0][r] = xc[r]; xb[1][r] = 0;
             ob[0][r] = ob[1][r] = 0;
         }
@@ -734,6 +740,16 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
         for (int a = 0; a <= WX; a++) kgb[a] = (unsigned)kg[a] * (unsigned)sizeof(real);
         const unsigned jb = (unsigned)j * (unsigned)sizeof(real);  // the lane's byte offset inside a half-row; the rim lanes': the pair right / left
         const unsigned jbR = (unsigned)(j + (rimR ? 1 : 0)) * (unsigned)sizeof(real), jbL = (unsigned)(j + (rimL ? (j ? -1 : M - 1) : 0)) * (unsigned)sizeof(real);
+        if constexpr (DEPTH == 2) {  // what step z0 - 1 would have requested: the column of plane z0 + 2, f of plane z0 + 1 (clamped like the loop's)
+            const auto rv0 = plane_rsrc<real>(pv, sxy, 3), rf0 = plane_rsrc<real>(pf, sxy, 2);
+            const int e2 = min(2, z1 - z0) * sxy, e1 = min(1, z1 - z0) * sxy;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int qn = Q0 ^ 1 ^ (r & 1);
+                c[3][r] = buf_load<real>(rv0, jb, roff[r] + e2 + qn * H);
+                fb[1][r] = FNT ? buf_load_nt<real>(rf0, jb, roff[r] + e1 + qn * H) : buf_load<real>(rf0, jb, roff[r] + e1 + qn * H);
+            }
+        }
         {
             int z = z0;
             for (;;) {
@@ -753,11 +769,21 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
 #include "mgx_pipe_step.inc"
 #undef MGX_K
                 if (++z >= z1) break;
+                if constexpr (DEPTH == 2) {
+#define MGX_K 4
+#include "mgx_pipe_step.inc"
+#undef MGX_K
+                    if (++z >= z1) break;
+#define MGX_K 5
+#include "mgx_pipe_step.inc"
+#undef MGX_K
+                    if (++z >= z1) break;
+                }
             }
         }
-        const int kl = (z1 - z0 - 1) & 3;  // the last step: its results sit in ob[kl & 1], its row parity is (UNR - 1) ^ (kl & 1)
-        if (kl & 1) store_plane(-1, (UNR - 1) ^ 1, ob[1]);
-        else store_plane(-1, UNR - 1, ob[0]);
+        const int kl = (z1 - z0 - 1) & 1;  // the last step: its results sit in ob[kl], its row parity is Q0 ^ kl
+        if (kl) store_plane(-1, Q0 ^ 1, ob[1]);
+        else store_plane(-1, Q0, ob[0]);
     } else {
     for (int z = z0; z < z1; z++) {
         const bool more = z + 1 < z1;
@@ -2309,8 +2335,15 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
 #define MGX_PU(F, U)                                                                                                                    \
     MGX_LAUNCH((relax3d_xs_pipe_kernel<real, WX, WY, 2, F, 0, U>), gride, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, \
                hy2, hz2, colour, zce, gx, gy, xcd)
-            if (kind == 2 && WY == 8) { if (q0) MGX_PU(true, 2); else MGX_PU(true, 1); }
-            else { if (q0) MGX_PU(false, 2); else MGX_PU(false, 1); }
+            // bit 4: DEPTH 2 (the column and f requested two steps ahead: twice the bytes in flight)
+#define MGX_PUQ(F)                                                              \
+    do {                                                                        \
+        if (ctx->pipe_unroll & 16) { if (q0) MGX_PU(F, 4); else MGX_PU(F, 3); } \
+        else { if (q0) MGX_PU(F, 2); else MGX_PU(F, 1); }                       \
+    } while (0)
+            if (kind == 2 && WY == 8) MGX_PUQ(true);
+            else MGX_PUQ(false);
+#undef MGX_PUQ
 #undef MGX_PU
             return;
         }
@@ -3779,7 +3812,7 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         // tools/level_timing.py).  Bit 0: the correcting red pass, bit 1: the plain pass and the from-zero sweep (2 x 8 / 2 x 4 waves of
         // 2 rows), bit 2: the fp32 two-pair kernels; bits 0 and 1 apply to fp64 only (the fp32 one-pair kernels of the 257^3 level run
         // short runs in many workgroups and lose 10 % unrolled) unless bit 3 is set too (tests).  Default 7.
-        MGX_REQUIRE(value >= 0 && value <= 15, MGX_ERR_INVALID, "set_param: relax3d.unroll = %d not in [0, 15]", value);
+        MGX_REQUIRE(value >= 0 && value <= 31, MGX_ERR_INVALID, "set_param: relax3d.unroll = %d not in [0, 31]", value);
         ctx->pipe_unroll = value;
     } else if (!strcmp(name, "relax3d.zchunk")) {
         MGX_REQUIRE(value >= 0, MGX_ERR_INVALID, "relax3d.zchunk must be >= 0 (0 = automatic)");

@@ -51,15 +51,16 @@ def test_unrolled_plain_pass(ctx, dtype, n3):
     v = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
     f = rng.uniform(-1, 1, O.shape(n3)).astype(dtype)
     try:
-        ctx.set_param("relax3d.unroll", 15)
         ctx.set_param("relax3d.v2", 0)
         ctx.set_param("relax3d.lds", 3282)  # the 2 x 8 x 2 shape with non-temporal f on every size
-        for zchunk in (0, 2, 3, 5, 8):
-            ctx.set_param("relax3d.zchunk", zchunk)
-            for k in (1, 3):
-                want = O.relax3d(n3, RG, v, f, k, dtype=dtype)
-                assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, RG, k), want), (zchunk, k)
-                assert ctx.last_relax_kernel().startswith("relax3d_xs_pipe_kernel"), ctx.last_relax_kernel()
+        for unroll in (15, 31):  # 31: the column and f requested two steps ahead (six steps per loop trip)
+            ctx.set_param("relax3d.unroll", unroll)
+            for zchunk in (0, 2, 3, 5, 8):
+                ctx.set_param("relax3d.zchunk", zchunk)
+                for k in (1, 3):
+                    want = O.relax3d(n3, RG, v, f, k, dtype=dtype)
+                    assert bits_equal(P.ops3dxs.relax(ctx, v, f, n3, RG, k), want), (unroll, zchunk, k)
+                    assert ctx.last_relax_kernel().startswith("relax3d_xs_pipe_kernel"), ctx.last_relax_kernel()
     finally:
         ctx.set_param("relax3d.unroll", 7)
         ctx.set_param("relax3d.v2", 1)
