@@ -427,7 +427,9 @@ __device__ __forceinline__ real interp_xs_at(const real* __restrict__ coarse, in
                                      [&](int dx, int dy, int dz) { return c[XSplit::pos(gx + dx, CH) + dy * CP + (size_t)dz * CPL]; });
 }
 
-template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0, int UNR = 0>
+// CSP (diagnostic builds, TIMING ONLY, wrong results): the unrolled loop's loads and stores follow the access pattern of a colour-contiguous
+// layout (row pitch H, the colour's / the other colour's points of a plane in its first / second half) instead of the x-split one
+template <class real, int WX, int WY, int R, bool FNT = false, int VAR = 0, int UNR = 0, int CSP = 0>
 __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whatever the shape: 8-wave workgroups run two to a CU
     relax3d_xs_pipe_kernel(const real* __restrict__ vin, real* __restrict__ vout, const real* __restrict__ f, int sx, int sy,
                            int zbeg, int zend, real hx2, real hy2, real hz2, int colour, int zchunk, int gx, int gy,
@@ -738,6 +740,10 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
         unsigned kgb[WX + 1];  // CORR: byte offsets of the coarse entries this thread stages
 #pragma unroll
         for (int a = 0; a <= WX; a++) kgb[a] = (unsigned)kg[a] * (unsigned)sizeof(real);
+        // MGX_HO(par, own): offset of a row's half inside the plane -- x-split: the half of x parity `par`; CSP: the half-plane of the
+        // colour (own) or of the other colour; MGX_RO(off): the row's offset -- x-split: as computed (pitch P = 2 H); CSP: pitch H
+#define MGX_HO(par, own) (CSP ? ((own) ? colour : 1 - colour) * (H * sy) : (par) * H)
+#define MGX_RO(off) (CSP ? (off) / 2 : (off))
         const unsigned jb = (unsigned)j * (unsigned)sizeof(real);  // the lane's byte offset inside a half-row; the rim lanes': the pair right / left
         const unsigned jbR = (unsigned)(j + (rimR ? 1 : 0)) * (unsigned)sizeof(real), jbL = (unsigned)(j + (rimL ? (j ? -1 : M - 1) : 0)) * (unsigned)sizeof(real);
         if constexpr (DEPTH == 2) {  // what step z0 - 1 would have requested: the column of plane z0 + 2, f of plane z0 + 1 (clamped like the loop's)
@@ -784,6 +790,8 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
         const int kl = (z1 - z0 - 1) & 1;  // the last step: its results sit in ob[kl], its row parity is Q0 ^ kl
         if (kl) store_plane(-1, Q0 ^ 1, ob[1]);
         else store_plane(-1, Q0, ob[0]);
+#undef MGX_HO
+#undef MGX_RO
     } else {
     for (int z = z0; z < z1; z++) {
         const bool more = z + 1 < z1;
@@ -2328,7 +2336,12 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
     note_relax_kernel<real>(ctx, kind ? "relax3d_xs_pipe_kernel" : "relax3d_xs_lds_kernel", WX, WY, R, kind == 2 && R == 2 && WX * WY == 16);
     // the shapes the automatic choice takes (2 x 8 and 2 x 4 waves of 2 rows): the step loop unrolled four times (see the kernel); the
     // launch hands every run an even number of planes so that all runs start with the row parity the instantiation is compiled for
-    if constexpr (R == 2 && WX == 2 && (WY == 8 || WY == 4)) {
+#ifdef MGX_DIAGNOSTICS
+    constexpr bool full_row_shape = WX == 4 && WY == 4;  // tiles of 256 pairs x 8 rows: timing experiments only
+#else
+    constexpr bool full_row_shape = false;
+#endif
+    if constexpr (R == 2 && ((WX == 2 && (WY == 8 || WY == 4)) || full_row_shape)) {
         if (kind >= 1 && (ctx->pipe_unroll & 2) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8))) {
             const int zce = zchunk + (zchunk & 1), q0 = (colour + 1 + zbeg) & 1;
             const dim3 gride((unsigned)gx * gy * ceil_div(zend - zbeg, zce));
@@ -2336,6 +2349,13 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
     MGX_LAUNCH((relax3d_xs_pipe_kernel<real, WX, WY, 2, F, 0, U>), gride, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, \
                hy2, hz2, colour, zce, gx, gy, xcd)
             // bit 4: DEPTH 2 (the column and f requested two steps ahead: twice the bytes in flight)
+#ifdef MGX_DIAGNOSTICS
+            if (ctx->relax_ablate == 77) {  // TIMING ONLY: the access pattern of a colour-contiguous layout (wrong results)
+                if (kind == 2 && WY == 8) MGX_LAUNCH((relax3d_xs_pipe_kernel<real, WX, WY, 2, true, 0, 1, 1>), gride, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zce, gx, gy, xcd);
+                else MGX_LAUNCH((relax3d_xs_pipe_kernel<real, WX, WY, 2, false, 0, 1, 1>), gride, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, hy2, hz2, colour, zce, gx, gy, xcd);
+                return;
+            }
+#endif
 #define MGX_PUQ(F)                                                              \
     do {                                                                        \
         if (ctx->pipe_unroll & 16) { if (q0) MGX_PU(F, 4); else MGX_PU(F, 3); } \

@@ -164,16 +164,14 @@ __global__ void __launch_bounds__(64 * TYW, 4)  // four waves per SIMD (128 VGPR
             if (moreR) vX[o] = buf_load<real>(rv, off[hr], roff[o] + 3 * PL);
             const bool full = o == 0 ? res0 : res1;
             if (moreF && full) fX[o][1 - hr] = buf_load<real>(rf, off[1 - hr], roff[o] + 2 * PL);
-            // an entry no pass writes (a boundary row or plane; the x-face entry of the even half): v itself.  Row and plane are
-            // uniform; the x-face is a matter of ONE lane of the first / last tile column -- that lane's load follows, under its
-            // own exec mask, the load every lane makes (a choice of the DESCRIPTOR by lane makes the compiler loop over the
-            // descriptors in every iteration: ~30 scalar and vector instructions in the issue phase)
-            if (moreK && (!yint[o] || g + 2 == sz - 1)) {
+            // an entry no pass writes: v itself.  (The x-face entry is a matter of ONE lane, and the choice of the descriptor by lane makes
+            // hipcc loop over the descriptors (~30 instructions per iteration).  Round 4 tried the lane's load under its own exec mask
+            // behind / beside the load every lane makes: the compiler then loads into a temporary and copies it into place behind an
+            // s_waitcnt vmcnt(0) in mid-iteration -- 614 against 570 us.  The loop stays.)
+            if (moreK && (!yint[o] || g + 2 == sz - 1 || (hr == 0 && xbl)))
                 fX[o][hr] = buf_load<real>(rv, off[hr], roff[o] + 2 * PL);
-            } else {
-                if (moreF && (full || o == 1 || rlx0)) fX[o][hr] = buf_load<real>(rf, off[hr], roff[o] + 2 * PL);
-                if (hr == 0 && moreK && xbl) fX[o][hr] = buf_load<real>(rv, off[hr], roff[o] + 2 * PL);
-            }
+            else if (moreF && (full || o == 1 || rlx0))
+                fX[o][hr] = buf_load<real>(rf, off[hr], roff[o] + 2 * PL);
             if (o == 1 && bot && moreK) fX[1][1 - hr] = buf_load<real>(rv, off[hr], roffD + 2 * PL);  // the row below, red there
         }
         __builtin_amdgcn_s_setprio(0);
