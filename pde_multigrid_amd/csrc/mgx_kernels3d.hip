@@ -2260,6 +2260,12 @@ __global__ void __launch_bounds__(1024) residual_sumsq_final_kernel(const double
 
 // =========================================================================== host side
 static inline dim3 blk() { return dim3(64, 4, 1); }
+// the kernels that address planes through buffer descriptors (the unrolled step loops: mgx_pipe_step.inc) cover up to four planes with
+// one 32-bit range: levels whose planes are larger than that stay on the rolled kernels (64-bit pointers)
+template <class real>
+static inline bool planes_fit_descriptor(int sx, int sy) {
+    return (unsigned long long)Geo<XSplit, real>(sx, sy).PL * sizeof(real) * 4ull < (1ull << 32);
+}
 static inline dim3 grd(int nx, int ny, int nz) { return dim3(ceil_div(nx, 64), ceil_div(ny, 4), nz); }
 
 static int check_n3(const int n[3], const char* what) {
@@ -2342,7 +2348,7 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
     constexpr bool full_row_shape = false;
 #endif
     if constexpr (R == 2 && ((WX == 2 && (WY == 8 || WY == 4)) || full_row_shape)) {
-        if (kind >= 1 && (ctx->pipe_unroll & 2) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8))) {
+        if (kind >= 1 && (ctx->pipe_unroll & 2) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8)) && planes_fit_descriptor<real>(sx, sy)) {
             const int zce = zchunk + (zchunk & 1), q0 = (colour + 1 + zbeg) & 1;
             const dim3 gride((unsigned)gx * gy * ceil_div(zend - zbeg, zce));
 #define MGX_PU(F, U)                                                                                                                    \
@@ -2429,7 +2435,7 @@ static bool relax3d_xs_pass_lds(mgx_ctx* ctx, real* v, const real* f, int sx, in
         const int xcd = ctx->relax_xcd == 1 ? 1 : 0;
         const dim3 grid2((unsigned)gx2 * gy2 * gz2);
         note_relax_kernel<real>(ctx, "relax3d_xs_pipe_v2_kernel", 2, 8, 2, fnt);
-        if (ctx->pipe_unroll & 4) {  // the step loop unrolled four times (runs of an even number of planes, entry parity q0)
+        if ((ctx->pipe_unroll & 4) && planes_fit_descriptor<real>(sx, sy)) {  // the step loop unrolled four times (runs of an even number of planes, entry parity q0)
             const int zce = zchunk + (zchunk & 1), q0 = (colour + 1 + zbeg) & 1;
             const dim3 gride((unsigned)gx2 * gy2 * ceil_div(zend - zbeg, zce));
 #define MGX_PU2(F, U)                                                                                                                  \
@@ -2518,7 +2524,7 @@ static bool relax3d_xs_first_sweep_zero(mgx_ctx* ctx, real* v, const real* f, in
 #define MGX_Z1U(WYY, F, U)                                                                                                         \
     MGX_LAUNCH((relax3d_xs_pipe_kernel<real, 2, WYY, 2, F, 3, U>), gride, dim3(64, 2 * WYY, 1), 0, ctx->compute, f, v, f, sx, sy, zbeg, zend, \
                        hx2, hy2, hz2, 1, zce, gx, gy, xcd, (const real*)nullptr, 0, 0, sz, 0)
-    if ((ctx->pipe_unroll & 2) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8))) {  // the step loop unrolled four times: runs of an even number of planes, entry parity (colour 1 + 1 + zbeg) & 1
+    if ((ctx->pipe_unroll & 2) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8)) && planes_fit_descriptor<real>(sx, sy)) {  // the step loop unrolled four times: runs of an even number of planes, entry parity (colour 1 + 1 + zbeg) & 1
         const int zce = zchunk + (zchunk & 1), q0 = (1 + 1 + zbeg) & 1;
         const dim3 gride((unsigned)gx * gy * ceil_div(zend - zbeg, zce));
         if (low) { if (q0) MGX_Z1U(4, false, 2); else MGX_Z1U(4, false, 1); }
@@ -3249,7 +3255,7 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
                  fnt2 ? "true" : "false");
         memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
         const dim3 grid2((unsigned)gx2 * gy2 * gz2);
-        if (ctx->pipe_unroll & 4) {
+        if ((ctx->pipe_unroll & 4) && planes_fit_descriptor<real>(sx, sy)) {
             const int zce = zchunk + (zchunk & 1), q0 = (colour + 1 + zb) & 1;
             const dim3 gride((unsigned)gx2 * gy2 * ceil_div(ze - zb, zce));
 #define MGX_CU2(F, U)                                                                                                                   \
@@ -3301,7 +3307,7 @@ static void corr_red_launch(mgx_ctx* ctx, real* v, const real* f, int sx, int sy
     snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,2,8,2,%s,2>", sizeof(real) == 8 ? "double" : "float",
              fnt ? "true" : "false");
     memcpy(ctx->last_corr_kernel, ctx->last_relax_kernel, sizeof ctx->last_corr_kernel);
-    if ((ctx->pipe_unroll & 1) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8))) {
+    if ((ctx->pipe_unroll & 1) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8)) && planes_fit_descriptor<real>(sx, sy)) {
         // the step loop unrolled four times, register roles and row parity fixed per step: runs of an even number of planes, so
         // that every run starts with the row parity q0 the instantiation is compiled for
         const int zce = zchunk + (zchunk & 1), q0 = (colour + 1 + zb) & 1;
@@ -3831,7 +3837,8 @@ int mgx_ctx_set_param(mgx_ctx* ctx, const char* name, int value) {
         // the pipelined smoother's step loop unrolled four times with fixed register roles (same loads, stores, arithmetic; measured:
         // tools/level_timing.py).  Bit 0: the correcting red pass, bit 1: the plain pass and the from-zero sweep (2 x 8 / 2 x 4 waves of
         // 2 rows), bit 2: the fp32 two-pair kernels; bits 0 and 1 apply to fp64 only (the fp32 one-pair kernels of the 257^3 level run
-        // short runs in many workgroups and lose 10 % unrolled) unless bit 3 is set too (tests).  Default 7.
+        // short runs in many workgroups and lose 10 % unrolled) unless bit 3 is set too (tests); bit 4: the plain pass requests its
+        // column and f TWO steps ahead (six steps per loop trip; measured 2 % slower, kept for the record).  Default 7.
         MGX_REQUIRE(value >= 0 && value <= 31, MGX_ERR_INVALID, "set_param: relax3d.unroll = %d not in [0, 31]", value);
         ctx->pipe_unroll = value;
     } else if (!strcmp(name, "relax3d.zchunk")) {

@@ -288,6 +288,8 @@ __global__ void __launch_bounds__(64 * TYW, 4)  // four waves per SIMD (128 VGPR
 // fp32 moves half the bytes with the same instructions and is no faster than its separate launches (513^3: 0.91 / 0.87 ms).
 bool relax_rr3d_xs_takes(const mgx_ctx* ctx, const int n[3], const int cn[3], size_t elem) {
     if (!ctx->rr_black || cn[0] < 3 || cn[1] < 3 || cn[2] < 3) return false;
+    // the kernel addresses up to four fine planes through one buffer descriptor (a 32-bit range)
+    if ((unsigned long long)(elem == 8 ? Geo<XSplit, double>(n[0], n[1]).PL : Geo<XSplit, float>(n[0], n[1]).PL) * elem * 4ull >= (1ull << 32)) return false;
     return ctx->rr_black == 2 || (elem == 8 && n[0] >= 385 && n[1] >= 129 && n[2] >= 65);
 }
 
