@@ -157,10 +157,24 @@ def run_secondary(P, ctx, np):
         known = json.load(fh)
     out = {}
 
-    def run(name, key, make, dim, nsz, nlev, steps):
+    def run(name, key, make, dim, nsz, nlev, steps, smoother_bytes=0):
         mg = make()
         ka = known.get(key)
         mg.VCycle(0, 2, 2)
+        roof = None
+        if smoother_bytes:  # the smoother of this hierarchy's finest level alone, as the headline's `roofline` is taken (HIP events)
+            e0, e1 = ctx.event(), ctx.event()
+            mg.Relax(0, 2)
+            ctx.sync()
+            ctx.record(e0)
+            for _ in range(10):
+                mg.Relax(0, 2)
+            ctx.record(e1)
+            launch_s = ctx.elapsed_ms(e0, e1) * 1e-3 / 40  # 10 calls x 2 sweeps x 2 colours
+            per_launch = 3 * smoother_bytes * (nsz - 2) ** 3 / 2.0
+            roof = {"bound": "hbm", "kernel": ctx.last_relax_kernel(), "avg_launch_us": round(launch_s * 1e6, 2),
+                    "algorithmic_bytes_per_launch": per_launch, "achieved": round(per_launch / launch_s / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9,
+                    "unit": "GB/s", "frac": round(per_launch / launch_s / HBM_PEAK_BPS, 4), "traffic": None}
         ts = []
         for _ in range(3):
             ctx.sync()
@@ -180,13 +194,15 @@ def run_secondary(P, ctx, np):
         status = "no known answer" if ka is None else ("ok" if ("%016x" % s1, "%016x" % s2) == (ka["sum64"], ka["wsum64"]) else "MISMATCH")
         out[name] = {"ms_per_cycle": round(t * 1e3, 4), "min_ms": round(min(ts) * 1e3, 4), "mlups": round(lups / t / 1e6, 1),
                      "steps": steps, "result_check": status, "known_answer": key}
+        if roof:
+            out[name]["roofline"] = roof
 
     run("configs[1]: 2D Lyapunov 1025^2, 7 levels, f64, V(2,2)", "2d_n1025_vcycle22_7lev_f64",
         lambda: P.MultiGrid2D(ctx, [1025] * 2, [0, 1, 0, 1], [-1, -2, 0, -3], 2, np.float64, nlevels=7), 2, 1025, 7, 200)
     run("configs[2]: 3D Poisson 257^3, 6 levels, f64, V(2,2)", "3d_n257_vcycle22_6lev_f64",
         lambda: P.MultiGrid3D(ctx, [257] * 3, R3, np.float64, nlevels=6), 3, 257, 6, 50)
     run("3D Poisson 513^3, 9 levels, f32 (the reference's precision), V(2,2)", "3d_n513_vcycle22_9lev_f32",
-        lambda: P.MultiGrid3D(ctx, [513] * 3, R3, np.float32), 3, 513, 9, 20)
+        lambda: P.MultiGrid3D(ctx, [513] * 3, R3, np.float32), 3, 513, 9, 20, smoother_bytes=4)
     # the reference's PUBLISHED workload (thesis Fig. 4.4 = BASELINE.md section 1: whole-program wall time, fp32): construction + RHS +
     # FMG(2, 3000, 3000) + download, n = 129; the thesis' GPU (GeForce GTX 550 Ti) took 39.1 s, its CPU run stopped at n = 65 (213.4 s)
     key = "3d_n129_fmg_2_3000_3000_f32"
