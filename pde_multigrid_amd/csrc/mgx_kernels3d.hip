@@ -941,7 +941,11 @@ __global__ void __launch_bounds__(64 * WX * WY)
     constexpr bool CORR = VAR == 2;
     static_assert(!CORR || R == 2, "the correcting variant is written for 2 rows per lane");
     static_assert(!CORR || (WX * WY >= WY * R / 2 + 1 && WY > 1), "one wave per coarse row under the tile and its rim");
-    constexpr int KR = WY * R / 2 + 1, NK = 2 * WX, KC = 64 * NK + 2;  // coarse rows / columns staged per plane
+    // EDGEF (the unrolled form): the row a tile reads above / below itself is corrected on the fly by the edge waves, from one more
+    // staged coarse row, as in relax3d_xs_pipe_kernel -- no set P, no pre-pass; the rolled form keeps the tile's first / last row in P
+    constexpr bool EDGEF = CORR && UNR != 0;
+    constexpr int KR = WY * R / 2 + 1 + (EDGEF ? 1 : 0), NK = 2 * WX, KC = 64 * NK + 2;  // coarse rows / columns staged per plane
+    static_assert(!CORR || WX * WY >= KR, "one wave per staged coarse row");
     __shared__ vec2 ey[2][WY][WX][2][64];
     __shared__ real ex[2][WY][WX][2][R];  // [lane 0's element 0 / lane 63's element 1]
     __shared__ real sK[CORR ? 3 : 1][CORR ? KR : 1][CORR ? KC : 1];
@@ -1001,13 +1005,38 @@ __global__ void __launch_bounds__(64 * WX * WY)
     bool rimc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const bool rowP = (wy == 0 && r == 0) || (wy == WY - 1 && r == R - 1);
+        const bool rowP = !EDGEF && ((wy == 0 && r == 0) || (wy == WY - 1 && r == R - 1));
         own0[r] = CORR && lane_on && !rowP && y0 + r <= sy - 2;
         own1[r] = CORR && lane_on && !rowP && y0 + r <= sy - 2;
         // the value taken from the neighbouring tile (left: x = 2 j0 - 1, right: x = 2 j0 + 4) is corrected by the lane that reads
         // it, as in relax3d_xs_pipe_kernel: no tile-edge columns in the set P
         rimc[r] = CORR && lane_on && !rowP && y0 + r <= sy - 2 && ((lane == 0 && wx == 0 && j0 > 0) || (lane == 63 && wx == WX - 1 && j0 + 2 < M - 1));
     }
+    const bool edgeN = EDGEF && lane_on && wy == 0 && y0 - 1 >= 1, edgeS = EDGEF && lane_on && wy == WY - 1 && y0 + R <= sy - 2;
+    // the corrections of the two edge-row values of plane zz this lane reads (wave row 0: the row above, y0 - 1, even: the staged row of
+    // the wave's first row; last wave row: the row below, y0 + R, odd: between the next two staged rows); qq = parity of row 0 at zz:
+    // the entries are x = 2 (j0 + p) + qq above, x = 2 (j0 + p) + (qq ^ 1) below (R = 2), p = 0, 1
+#define MGX_CORR_EDGE2(qq, zz, e)                                                                                   \
+    do {                                                                                                            \
+        const real* k0_ = &sK[0][0][0] + ((zz) >> 1) % 3 * (KR * KC) + kmy;                                         \
+        const real* k1_ = &sK[0][0][0] + (((zz) >> 1) + 1) % 3 * (KR * KC) + kmy;                                   \
+        const bool below_ = wy != 0;                                                                                \
+        const int xp_ = below_ ? ((qq) ^ 1) & 1 : (qq) & 1;                                                         \
+        const int ro_ = below_ ? KC : 0;                                                                            \
+        auto g0_ = [&](int dx, int dy, int dz) { return (dz ? k1_ : k0_)[ro_ + dy * KC + dx]; };                    \
+        auto g1_ = [&](int dx, int dy, int dz) { return (dz ? k1_ : k0_)[ro_ + 1 + dy * KC + dx]; };                \
+        switch ((below_ ? 4 : 0) + xp_ * 2 + ((zz) & 1)) {                                                          \
+            case 0: e.x = interpolate3d_point<real>(0, 0, 0, g0_); e.y = interpolate3d_point<real>(0, 0, 0, g1_); break; \
+            case 1: e.x = interpolate3d_point<real>(0, 0, 1, g0_); e.y = interpolate3d_point<real>(0, 0, 1, g1_); break; \
+            case 2: e.x = interpolate3d_point<real>(1, 0, 0, g0_); e.y = interpolate3d_point<real>(1, 0, 0, g1_); break; \
+            case 3: e.x = interpolate3d_point<real>(1, 0, 1, g0_); e.y = interpolate3d_point<real>(1, 0, 1, g1_); break; \
+            case 4: e.x = interpolate3d_point<real>(0, 1, 0, g0_); e.y = interpolate3d_point<real>(0, 1, 0, g1_); break; \
+            case 5: e.x = interpolate3d_point<real>(0, 1, 1, g0_); e.y = interpolate3d_point<real>(0, 1, 1, g1_); break; \
+            case 6: e.x = interpolate3d_point<real>(1, 1, 0, g0_); e.y = interpolate3d_point<real>(1, 1, 0, g1_); break; \
+            default: e.x = interpolate3d_point<real>(1, 1, 1, g0_); e.y = interpolate3d_point<real>(1, 1, 1, g1_); break; \
+        }                                                                                                           \
+        if (!(xp_ | j0)) e.x = 0; /* x = 0: a boundary entry */                                                     \
+    } while (0)
 #define MGX_K2_REQUEST(plane)                                                                   \
     do {                                                                                        \
         if (kload) {                                                                            \
@@ -1108,6 +1137,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
     }
     MGX_LOAD_RIM2(0, q, xc, Nc, Sc);
     real er0 = 0;
+    vec2 ee0 = {0, 0};
     int rr0 = 0;
     if constexpr (CORR) {
         // own entries of the planes z0-1, z0, z0+1: the correction straight from the coarse array, once per run of planes
@@ -1132,6 +1162,26 @@ __global__ void __launch_bounds__(64 * WX * WY)
         rr0 = wx == 0 ? ((q ^ 1) & 1) : 1 - ((q ^ 1) & 1);
         if (rimc[rr0] && z0 + 1 <= szg - 2)
             er0 = interp_xs_at<real>(coarse, CH, CP, CPL, wx == 0 ? 2 * j0 - 1 : 2 * j0 + 4, y0 + rr0, z0 + 1);
+        if constexpr (EDGEF) {  // the edge-row values of plane z0 (corrected here) and of plane z0 + 1 (ee0: added when they have arrived)
+            if (edgeN) {
+                if (q | j0) Nc.x = Nc.x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + q, y0 - 1, z0);
+                Nc.y = Nc.y + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + q, y0 - 1, z0);
+            }
+            if (edgeS) {
+                if ((q ^ 1) | j0) Sc.x = Sc.x + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + (q ^ 1), y0 + R, z0);
+                Sc.y = Sc.y + interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + (q ^ 1), y0 + R, z0);
+            }
+            if (z0 + 1 <= szg - 2) {
+                if (edgeN) {
+                    if ((q ^ 1) | j0) ee0.x = interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + (q ^ 1), y0 - 1, z0 + 1);
+                    ee0.y = interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + (q ^ 1), y0 - 1, z0 + 1);
+                }
+                if (edgeS) {
+                    if (q | j0) ee0.x = interp_xs_at<real>(coarse, CH, CP, CPL, 2 * j0 + q, y0 + R, z0 + 1);
+                    ee0.y = interp_xs_at<real>(coarse, CH, CP, CPL, 2 * (j0 + 1) + q, y0 + R, z0 + 1);
+                }
+            }
+        }
         // the coarse planes under the arrivals of the first three steps (the loop's requests start with the fourth)
         MGX_K2_REQUEST(min((z0 + 2) >> 1, ckmax));
         MGX_K2_STORE((z0 + 2) >> 1);
@@ -1298,6 +1348,7 @@ __global__ void __launch_bounds__(64 * WX * WY)
 #undef MGX_K2_STORE
 #undef MGX_CORR_PAIR2
 #undef MGX_CORR_RIM2
+#undef MGX_CORR_EDGE2
 }
 
 // ------------------------------------------------------------------ relax, whole small level in one workgroup
@@ -3229,6 +3280,7 @@ static void corr_pset_launch(mgx_ctx* ctx, real* v, int sx, int sy, int fzoff, c
     if (pzend <= pzbeg) return;
     const int nk = (cn[1] - 2) / PH + 1;
     if (PW != 256) return;  // relax3d_xs_pipe_kernel<.., 2> corrects everything it reads itself: its set P is empty
+    if ((ctx->pipe_unroll & 4) && planes_fit_descriptor<real>(sx, sy)) return;  // and so does the unrolled two-pair kernel (mgx_pipe2_step.inc)
     MGX_LAUNCH((correct_pset3d_xs_kernel<real>), dim3(ceil_div(M - 1, 64), ceil_div(nk, 4), pzend - pzbeg), blk(), 0, ctx->compute, v,
                        sx, sy, coarse_v, cn[0], cn[1], PW, PH, 0, fzoff, czoff, pzbeg, zmin, zmax);
     // no column part any more: both correcting kernels correct the values they take from the neighbouring tile themselves
