@@ -2402,6 +2402,9 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
         if (kind >= 1 && (ctx->pipe_unroll & 2) && (sizeof(real) == 8 || (ctx->pipe_unroll & 8)) && planes_fit_descriptor<real>(sx, sy)) {
             const int zce = zchunk + (zchunk & 1), q0 = (colour + 1 + zbeg) & 1;
             const dim3 gride((unsigned)gx * gy * ceil_div(zend - zbeg, zce));
+            // the name rocprofv3 shows carries <..., VAR = 0, UNR = 1 / 2 by q0 (3 / 4: two steps ahead), CSP = 0>
+            snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,%d,%d,2,%s,0,unrolled%s>", sizeof(real) == 8 ? "double" : "float",
+                     WX, WY, kind == 2 && WY == 8 ? "true" : "false", (ctx->pipe_unroll & 16) ? " depth 2" : "");
 #define MGX_PU(F, U)                                                                                                                    \
     MGX_LAUNCH((relax3d_xs_pipe_kernel<real, WX, WY, 2, F, 0, U>), gride, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, \
                hy2, hz2, colour, zce, gx, gy, xcd)
