@@ -793,124 +793,124 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
 #undef MGX_HO
 #undef MGX_RO
     } else {
-    for (int z = z0; z < z1; z++) {
-        const bool more = z + 1 < z1;
-        // a wave that has passed the barrier issues its stores and next loads at raised priority: requests leave the CU
-        // before the other waves' arithmetic (measured -1.3 % per pass, same-box A/B)
-        __builtin_amdgcn_s_setprio(3);
-        if (z > z0) store_plane(-1, q ^ 1, op);  // results of plane z-1
-        if constexpr (ZERO1) {  // the red entries of the lane's own pairs at plane z (x = 0 is a boundary point)
+        for (int z = z0; z < z1; z++) {
+            const bool more = z + 1 < z1;
+            // a wave that has passed the barrier issues its stores and next loads at raised priority: requests leave the CU
+            // before the other waves' arithmetic (measured -1.3 % per pass, same-box A/B)
+            __builtin_amdgcn_s_setprio(3);
+            if (z > z0) store_plane(-1, q ^ 1, op);  // results of plane z-1
+            if constexpr (ZERO1) {  // the red entries of the lane's own pairs at plane z (x = 0 is a boundary point)
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int qo = 1 - (q ^ (r & 1));
-                if (lane_on && (qo | j) && r < nrows) __builtin_nontemporal_store(cc[r], &po[roff[r] + qo * H + j]);
-            }
-        }
-        if (more) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int qn = q ^ 1 ^ (r & 1);  // row parity in plane z+1
-                cn[r] = pv[roff[r] + 2 * sxy + qn * H + j];
-                fn[r] = (FNT ? __builtin_nontemporal_load(&pf[roff[r] + sxy + qn * H + j]) : pf[roff[r] + sxy + qn * H + j]);
-            }
-            MGX_LOAD_RIM(1, q ^ 1, xn, Nn, Sn);
-            if constexpr (CORR) {
-                // the correction of the plane that arrives in step s is formed in step s itself, BEFORE its barrier, from the
-                // coarse planes (s + 2) >> 1 and, for odd s, (s + 3) / 2: that one is requested in step s - 3 (these are
-                // the LAST loads of the step: they stay in flight over the step's end), stored at the end of step s - 2
-                // and so visible from the barrier of step s - 1 on
-                if (!(z & 1) && z + 4 < z1) MGX_K_REQUEST(min((z >> 1) + 3, ckmax));
-            }
-            publish((z + 1) & 1, cu);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        const int slot = z & 1;
-        const real Nl = ey[slot][wyN][wx][1][lane], Sl = ey[slot][wyS][wx][0][lane];
-        const real Nedge = wy > 0 ? Nl : Nc;
-        const real Sedge = wy < WY - 1 ? Sl : Sc;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int qr = q ^ (r & 1);
-            const real fromR = ex[slot][wy][wxR][0][r], fromL = ex[slot][wy][wxL][1][r];
-            real nb = qr ? __shfl_down(cc[r], 1, 64) : __shfl_up(cc[r], 1, 64);
-            if (qr) {
-                if (lane == 63) nb = fromR;
-                if (rimR) nb = xc[r];
-            } else {
-                if (lane == 0) nb = fromL;
-                if (rimL) nb = xc[r];
-            }
-            const real W = qr ? cc[r] : nb;
-            const real E = qr ? nb : cc[r];
-            const real N = r == 0 ? Nedge : cc[r - 1];
-            const real S = r == R - 1 ? Sedge : cc[r + 1];
-            oc[r] = relax3d_point_rd<real>(W, E, N, S, cp[r], cu[r], fc[r], hx2, hy2, hz2, rd);
-        }
-        real en[R];   // CORR: the correction of the entries that are on their way (plane z + 2, x = 2j + qn) ...
-        bool dc[R];   // ... if they get one
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            en[r] = 0;
-            dc[r] = false;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        real er = 0, ee = 0;  // CORR: the corrections of the rim value (row rrim) and of the edge-row value that are on their way (plane z + 1)
-        int rrim = 0;
-        if constexpr (CORR) {
-            if (more) {
-                MGX_CORR_PAIR(q ^ 1, z + 2, en[0], en[1]);  // all lanes: the staged tile covers every lane's cell
-#pragma unroll
-                for (int r = 0; r < R; r++) dc[r] = own[r] && z + 2 <= szg - 2 && ((q ^ 1 ^ (r & 1)) | j);
-                if (z == z0) {
-                    er = er0;
-                    rrim = rr0;
-                    ee = ee0;
-                } else {
-                    if (wx == 0 || wx == WX - 1) MGX_CORR_RIM(q ^ 1, z + 1, rrim, er);
-                    if (wy == 0 || wy == WY - 1) MGX_CORR_EDGE(q ^ 1, z + 1, ee);
+                for (int r = 0; r < R; r++) {
+                    const int qo = 1 - (q ^ (r & 1));
+                    if (lane_on && (qo | j) && r < nrows) __builtin_nontemporal_store(cc[r], &po[roff[r] + qo * H + j]);
                 }
-                if (z + 1 > szg - 2) er = ee = 0;  // a boundary plane: no correction
             }
-        }
-        if (CORR && kload && more && !(z & 1) && z + 4 < z1) {
-            // the staging loads issued last in this step may stay in flight (loads return in order: at most WX + 1
-            // outstanding operations means everything issued before them has arrived); they are stored a step later
-            if constexpr (WX == 2) __builtin_amdgcn_s_waitcnt(0x0F73);
-            else __builtin_amdgcn_s_waitcnt(0x0F70);
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this step's prefetch and stores have had the whole step
-        }
+            if (more) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            cp[r] = cc[r];
-            cc[r] = cu[r];
-            cu[r] = dc[r] ? cn[r] + en[r] : cn[r];
-            fc[r] = fn[r];
-            xc[r] = (CORR && rimc[r] && r == rrim) ? xn[r] + er : xn[r];
-            op[r] = oc[r];
-        }
-        if constexpr (CORR) {
-            if ((z & 1) && z > z0 && z + 3 < z1) MGX_K_STORE(((z - 1) >> 1) + 3);  // requested in step z - 1
-        }
-        Nc = (CORR && edgeN) ? Nn + ee : Nn;
-        Sc = (CORR && edgeS) ? Sn + ee : Sn;
-        if constexpr (ZERO1) {  // what arrived in this step was f: the red values at those places (plane z + 2 / the rim of z + 1)
-            const int q1 = q ^ 1;  // the colour's half of row 0 at plane z + 1
+                for (int r = 0; r < R; r++) {
+                    const int qn = q ^ 1 ^ (r & 1);  // row parity in plane z+1
+                    cn[r] = pv[roff[r] + 2 * sxy + qn * H + j];
+                    fn[r] = (FNT ? __builtin_nontemporal_load(&pf[roff[r] + sxy + qn * H + j]) : pf[roff[r] + sxy + qn * H + j]);
+                }
+                MGX_LOAD_RIM(1, q ^ 1, xn, Nn, Sn);
+                if constexpr (CORR) {
+                    // the correction of the plane that arrives in step s is formed in step s itself, BEFORE its barrier, from the
+                    // coarse planes (s + 2) >> 1 and, for odd s, (s + 3) / 2: that one is requested in step s - 3 (these are
+                    // the LAST loads of the step: they stay in flight over the step's end), stored at the end of step s - 2
+                    // and so visible from the barrier of step s - 1 on
+                    if (!(z & 1) && z + 4 < z1) MGX_K_REQUEST(min((z >> 1) + 3, ckmax));
+                }
+                publish((z + 1) & 1, cu);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            const int slot = z & 1;
+            const real Nl = ey[slot][wyN][wx][1][lane], Sl = ey[slot][wyS][wx][0][lane];
+            const real Nedge = wy > 0 ? Nl : Nc;
+            const real Sedge = wy < WY - 1 ? Sl : Sc;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const int qn = q1 ^ (r & 1);
-                cu[r] = zred(cu[r], y0 + r >= sy - 1 || z + 2 >= szg - 1 || (qn == 0 && x0));
-                xc[r] = zred(xc[r], qn == 1 && j == M - 2);
+                const int qr = q ^ (r & 1);
+                const real fromR = ex[slot][wy][wxR][0][r], fromL = ex[slot][wy][wxL][1][r];
+                real nb = qr ? __shfl_down(cc[r], 1, 64) : __shfl_up(cc[r], 1, 64);
+                if (qr) {
+                    if (lane == 63) nb = fromR;
+                    if (rimR) nb = xc[r];
+                } else {
+                    if (lane == 0) nb = fromL;
+                    if (rimL) nb = xc[r];
+                }
+                const real W = qr ? cc[r] : nb;
+                const real E = qr ? nb : cc[r];
+                const real N = r == 0 ? Nedge : cc[r - 1];
+                const real S = r == R - 1 ? Sedge : cc[r + 1];
+                oc[r] = relax3d_point_rd<real>(W, E, N, S, cp[r], cu[r], fc[r], hx2, hy2, hz2, rd);
             }
-            Nc = zred(Nc, y0 - 1 <= 0 || (q1 == 0 && x0));
-            Sc = zred(Sc, y0 + R >= sy - 1 || ((q1 ^ ((R - 1) & 1)) == 0 && x0));
+            real en[R];   // CORR: the correction of the entries that are on their way (plane z + 2, x = 2j + qn) ...
+            bool dc[R];   // ... if they get one
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                en[r] = 0;
+                dc[r] = false;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            real er = 0, ee = 0;  // CORR: the corrections of the rim value (row rrim) and of the edge-row value that are on their way (plane z + 1)
+            int rrim = 0;
+            if constexpr (CORR) {
+                if (more) {
+                    MGX_CORR_PAIR(q ^ 1, z + 2, en[0], en[1]);  // all lanes: the staged tile covers every lane's cell
+#pragma unroll
+                    for (int r = 0; r < R; r++) dc[r] = own[r] && z + 2 <= szg - 2 && ((q ^ 1 ^ (r & 1)) | j);
+                    if (z == z0) {
+                        er = er0;
+                        rrim = rr0;
+                        ee = ee0;
+                    } else {
+                        if (wx == 0 || wx == WX - 1) MGX_CORR_RIM(q ^ 1, z + 1, rrim, er);
+                        if (wy == 0 || wy == WY - 1) MGX_CORR_EDGE(q ^ 1, z + 1, ee);
+                    }
+                    if (z + 1 > szg - 2) er = ee = 0;  // a boundary plane: no correction
+                }
+            }
+            if (CORR && kload && more && !(z & 1) && z + 4 < z1) {
+                // the staging loads issued last in this step may stay in flight (loads return in order: at most WX + 1
+                // outstanding operations means everything issued before them has arrived); they are stored a step later
+                if constexpr (WX == 2) __builtin_amdgcn_s_waitcnt(0x0F73);
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this step's prefetch and stores have had the whole step
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                cp[r] = cc[r];
+                cc[r] = cu[r];
+                cu[r] = dc[r] ? cn[r] + en[r] : cn[r];
+                fc[r] = fn[r];
+                xc[r] = (CORR && rimc[r] && r == rrim) ? xn[r] + er : xn[r];
+                op[r] = oc[r];
+            }
+            if constexpr (CORR) {
+                if ((z & 1) && z > z0 && z + 3 < z1) MGX_K_STORE(((z - 1) >> 1) + 3);  // requested in step z - 1
+            }
+            Nc = (CORR && edgeN) ? Nn + ee : Nn;
+            Sc = (CORR && edgeS) ? Sn + ee : Sn;
+            if constexpr (ZERO1) {  // what arrived in this step was f: the red values at those places (plane z + 2 / the rim of z + 1)
+                const int q1 = q ^ 1;  // the colour's half of row 0 at plane z + 1
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int qn = q1 ^ (r & 1);
+                    cu[r] = zred(cu[r], y0 + r >= sy - 1 || z + 2 >= szg - 1 || (qn == 0 && x0));
+                    xc[r] = zred(xc[r], qn == 1 && j == M - 2);
+                }
+                Nc = zred(Nc, y0 - 1 <= 0 || (q1 == 0 && x0));
+                Sc = zred(Sc, y0 + R >= sy - 1 || ((q1 ^ ((R - 1) & 1)) == 0 && x0));
+            }
+            pv += sxy;
+            pf += sxy;
+            po += sxy;
+            q ^= 1;
         }
-        pv += sxy;
-        pf += sxy;
-        po += sxy;
-        q ^= 1;
-    }
-    store_plane(-1, q ^ 1, op);  // the last plane
+        store_plane(-1, q ^ 1, op);  // the last plane
     }
 #undef MGX_LOAD_RIM
 #undef MGX_K_REQUEST
@@ -1241,106 +1241,106 @@ __global__ void __launch_bounds__(64 * WX * WY)
         if (kl & 1) store_plane(-1, (UNR - 1) ^ 1, ob[1]);
         else store_plane(-1, UNR - 1, ob[0]);
     } else {
-    for (int z = z0; z < z1; z++) {
-        const bool more = z + 1 < z1;
-        if (z > z0) store_plane(-1, q ^ 1, op);
-        if (more) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int qn = q ^ 1 ^ (r & 1);
-                cn[r] = MGX_LD2(pv, roff[r] + 2 * sxy + qn * H + j0);
-                fn[r] = FNT ? __builtin_nontemporal_load((const vec2*)&pf[roff[r] + sxy + qn * H + j0]) : MGX_LD2(pf, roff[r] + sxy + qn * H + j0);
-            }
-            MGX_LOAD_RIM2(1, q ^ 1, xn, Nn, Sn);
-            if constexpr (CORR) {
-                if (!(z & 1) && z + 4 < z1) MGX_K2_REQUEST(min((z >> 1) + 3, ckmax));  // the LAST loads of the step (see relax3d_xs_pipe_kernel)
-            }
-            publish((z + 1) & 1, cu);
-        }
-        const int slot = z & 1;
-        const vec2 Nl = ey[slot][wyN][wx][1][lane], Sl = ey[slot][wyS][wx][0][lane];
-        const vec2 Nedge = wy > 0 ? Nl : Nc;
-        const vec2 Sedge = wy < WY - 1 ? Sl : Sc;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int qr = q ^ (r & 1);
-            const real fromR = ex[slot][wy][wxR][0][r], fromL = ex[slot][wy][wxL][1][r];
-            // the x neighbour that is not the point's own pair: q_r = 1 -> E: element 0 takes the lane's element 1, element 1
-            // the next lane's element 0; q_r = 0 -> W: element 1 takes the lane's element 0, element 0 the previous lane's 1
-            real far;
-            if (qr) {
-                far = __shfl_down(cc[r].x, 1, 64);
-                if (lane == 63) far = fromR;
-                if (rimR) far = xc[r];
-            } else {
-                far = __shfl_up(cc[r].y, 1, 64);
-                if (lane == 0) far = fromL;
-                if (rimL) far = xc[r];
-            }
-            const vec2 N = r == 0 ? Nedge : cc[r > 0 ? r - 1 : 0];
-            const vec2 S = r == R - 1 ? Sedge : cc[r < R - 1 ? r + 1 : r];
-            const real W0 = qr ? cc[r].x : far, E0 = qr ? cc[r].y : cc[r].x;
-            const real W1 = qr ? cc[r].y : cc[r].x, E1 = qr ? far : cc[r].y;
-            oc[r].x = relax3d_point_rd<real>(W0, E0, N.x, S.x, cp[r].x, cu[r].x, fc[r].x, hx2, hy2, hz2, rd);
-            oc[r].y = relax3d_point_rd<real>(W1, E1, N.y, S.y, cp[r].y, cu[r].y, fc[r].y, hx2, hy2, hz2, rd);
-        }
-        real en0[R], en1[R];  // CORR: the corrections of the entries that are on their way (plane z + 2) ...
-        bool dc0[R], dc1[R];  // ... if they get one
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            en0[r] = en1[r] = 0;
-            dc0[r] = dc1[r] = false;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        real er = 0;
-        int rrim = 0;
-        if constexpr (CORR) {
+        for (int z = z0; z < z1; z++) {
+            const bool more = z + 1 < z1;
+            if (z > z0) store_plane(-1, q ^ 1, op);
             if (more) {
-                MGX_CORR_PAIR2(kmy, q ^ 1, z + 2, en0[0], en0[1]);
-                MGX_CORR_PAIR2(kmy + 1, q ^ 1, z + 2, en1[0], en1[1]);
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    dc0[r] = own0[r] && z + 2 <= szg - 2 && ((q ^ 1 ^ (r & 1)) | j0);
-                    dc1[r] = own1[r] && z + 2 <= szg - 2;
+                    const int qn = q ^ 1 ^ (r & 1);
+                    cn[r] = MGX_LD2(pv, roff[r] + 2 * sxy + qn * H + j0);
+                    fn[r] = FNT ? __builtin_nontemporal_load((const vec2*)&pf[roff[r] + sxy + qn * H + j0]) : MGX_LD2(pf, roff[r] + sxy + qn * H + j0);
                 }
-                if (z == z0) {
-                    er = er0;
-                    rrim = rr0;
-                } else if (wx == 0 || wx == WX - 1) {
-                    MGX_CORR_RIM2(q ^ 1, z + 1, rrim, er);
+                MGX_LOAD_RIM2(1, q ^ 1, xn, Nn, Sn);
+                if constexpr (CORR) {
+                    if (!(z & 1) && z + 4 < z1) MGX_K2_REQUEST(min((z >> 1) + 3, ckmax));  // the LAST loads of the step (see relax3d_xs_pipe_kernel)
                 }
-                if (z + 1 > szg - 2) er = 0;
+                publish((z + 1) & 1, cu);
             }
-        }
-        if (CORR && kload && more && !(z & 1) && z + 4 < z1) {
-            // the staging loads issued last in this step stay in flight (loads return in order: at most NK + 1 outstanding
-            // operations means everything issued before them has arrived); they are stored a step later
-            if constexpr (NK == 4) __builtin_amdgcn_s_waitcnt(0x0F75);
-            else __builtin_amdgcn_s_waitcnt(0x0F70);
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
+            const int slot = z & 1;
+            const vec2 Nl = ey[slot][wyN][wx][1][lane], Sl = ey[slot][wyS][wx][0][lane];
+            const vec2 Nedge = wy > 0 ? Nl : Nc;
+            const vec2 Sedge = wy < WY - 1 ? Sl : Sc;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            cp[r] = cc[r];
-            cc[r] = cu[r];
-            cu[r].x = dc0[r] ? cn[r].x + en0[r] : cn[r].x;
-            cu[r].y = dc1[r] ? cn[r].y + en1[r] : cn[r].y;
-            fc[r] = fn[r];
-            xc[r] = (CORR && rimc[r] && r == rrim) ? xn[r] + er : xn[r];
-            op[r] = oc[r];
+            for (int r = 0; r < R; r++) {
+                const int qr = q ^ (r & 1);
+                const real fromR = ex[slot][wy][wxR][0][r], fromL = ex[slot][wy][wxL][1][r];
+                // the x neighbour that is not the point's own pair: q_r = 1 -> E: element 0 takes the lane's element 1, element 1
+                // the next lane's element 0; q_r = 0 -> W: element 1 takes the lane's element 0, element 0 the previous lane's 1
+                real far;
+                if (qr) {
+                    far = __shfl_down(cc[r].x, 1, 64);
+                    if (lane == 63) far = fromR;
+                    if (rimR) far = xc[r];
+                } else {
+                    far = __shfl_up(cc[r].y, 1, 64);
+                    if (lane == 0) far = fromL;
+                    if (rimL) far = xc[r];
+                }
+                const vec2 N = r == 0 ? Nedge : cc[r > 0 ? r - 1 : 0];
+                const vec2 S = r == R - 1 ? Sedge : cc[r < R - 1 ? r + 1 : r];
+                const real W0 = qr ? cc[r].x : far, E0 = qr ? cc[r].y : cc[r].x;
+                const real W1 = qr ? cc[r].y : cc[r].x, E1 = qr ? far : cc[r].y;
+                oc[r].x = relax3d_point_rd<real>(W0, E0, N.x, S.x, cp[r].x, cu[r].x, fc[r].x, hx2, hy2, hz2, rd);
+                oc[r].y = relax3d_point_rd<real>(W1, E1, N.y, S.y, cp[r].y, cu[r].y, fc[r].y, hx2, hy2, hz2, rd);
+            }
+            real en0[R], en1[R];  // CORR: the corrections of the entries that are on their way (plane z + 2) ...
+            bool dc0[R], dc1[R];  // ... if they get one
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                en0[r] = en1[r] = 0;
+                dc0[r] = dc1[r] = false;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            real er = 0;
+            int rrim = 0;
+            if constexpr (CORR) {
+                if (more) {
+                    MGX_CORR_PAIR2(kmy, q ^ 1, z + 2, en0[0], en0[1]);
+                    MGX_CORR_PAIR2(kmy + 1, q ^ 1, z + 2, en1[0], en1[1]);
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        dc0[r] = own0[r] && z + 2 <= szg - 2 && ((q ^ 1 ^ (r & 1)) | j0);
+                        dc1[r] = own1[r] && z + 2 <= szg - 2;
+                    }
+                    if (z == z0) {
+                        er = er0;
+                        rrim = rr0;
+                    } else if (wx == 0 || wx == WX - 1) {
+                        MGX_CORR_RIM2(q ^ 1, z + 1, rrim, er);
+                    }
+                    if (z + 1 > szg - 2) er = 0;
+                }
+            }
+            if (CORR && kload && more && !(z & 1) && z + 4 < z1) {
+                // the staging loads issued last in this step stay in flight (loads return in order: at most NK + 1 outstanding
+                // operations means everything issued before them has arrived); they are stored a step later
+                if constexpr (NK == 4) __builtin_amdgcn_s_waitcnt(0x0F75);
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                cp[r] = cc[r];
+                cc[r] = cu[r];
+                cu[r].x = dc0[r] ? cn[r].x + en0[r] : cn[r].x;
+                cu[r].y = dc1[r] ? cn[r].y + en1[r] : cn[r].y;
+                fc[r] = fn[r];
+                xc[r] = (CORR && rimc[r] && r == rrim) ? xn[r] + er : xn[r];
+                op[r] = oc[r];
+            }
+            if constexpr (CORR) {
+                if ((z & 1) && z > z0 && z + 3 < z1) MGX_K2_STORE(((z - 1) >> 1) + 3);  // requested in step z - 1
+            }
+            Nc = Nn;
+            Sc = Sn;
+            pv += sxy;
+            pf += sxy;
+            po += sxy;
+            q ^= 1;
         }
-        if constexpr (CORR) {
-            if ((z & 1) && z > z0 && z + 3 < z1) MGX_K2_STORE(((z - 1) >> 1) + 3);  // requested in step z - 1
-        }
-        Nc = Nn;
-        Sc = Sn;
-        pv += sxy;
-        pf += sxy;
-        po += sxy;
-        q ^= 1;
-    }
-    store_plane(-1, q ^ 1, op);
+        store_plane(-1, q ^ 1, op);
     }
 #undef MGX_LOAD_RIM2
 #undef MGX_LD2
