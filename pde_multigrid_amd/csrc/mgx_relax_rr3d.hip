@@ -167,7 +167,9 @@ __global__ void __launch_bounds__(64 * TYW, 4)  // four waves per SIMD (128 VGPR
             // an entry no pass writes: v itself.  (The x-face entry is a matter of ONE lane, and the choice of the descriptor by lane makes
             // hipcc loop over the descriptors (~30 instructions per iteration).  Round 4 tried the lane's load under its own exec mask
             // behind / beside the load every lane makes: the compiler then loads into a temporary and copies it into place behind an
-            // s_waitcnt vmcnt(0) in mid-iteration -- 614 against 570 us.  The loop stays.)
+            // s_waitcnt vmcnt(0) in mid-iteration -- 614 against 570 us.  Both loads as inline assembly that updates the register in
+            // place removes loop, copy and wait (221 instead of 248 vector instructions per iteration) and is WRONG: the compiler moves
+            // a register whose pending load it does not know about (the 9^3 case of tests/test_gpu_relax_rr.py fails).  The loop stays.)
             if (moreK && (!yint[o] || g + 2 == sz - 1 || (hr == 0 && xbl)))
                 fX[o][hr] = buf_load<real>(rv, off[hr], roff[o] + 2 * PL);
             else if (moreF && (full || o == 1 || rlx0))
