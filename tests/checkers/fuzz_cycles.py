@@ -5,7 +5,7 @@ modes, both precisions, V-cycles and FMG, boxes with and without power-of-two sp
 
     python3 tests/checkers/fuzz_cycles.py [cases] [seed]
 MGX_PARAMS=name=value,... sets library parameters first (e.g. rr3d.black=2,relax3d.resident_min=1: the fused way down and
-the resident Relax kernel on every level that has the geometry); MGX_FUZZ_SWEEPS=n: sweep counts up to n - 1 (default 4).
+the resident Relax kernel on every level that has the geometry); MGX_FUZZ_SWEEPS=n: sweep counts up to n - 1 (default 4); MGX_FUZZ_WIDE=1: extents of 513 and 1025 points too.
 """
 import os
 import sys
@@ -25,6 +25,8 @@ for kv in filter(None, os.environ.get("MGX_PARAMS", "").split(",")):
     ctx.set_param(kv.split("=")[0], int(kv.split("=")[1]))
 SWEEPS = int(os.environ.get("MGX_FUZZ_SWEEPS", "4"))
 SZ = [3, 5, 9, 17, 33, 65, 129, 257]
+if os.environ.get("MGX_FUZZ_WIDE"):  # rows of 513 / 1025 points too (the fp32 two-pair kernels take rows of >= 513 points)
+    SZ = SZ + [513, 513, 1025]
 bad = 0
 for c in range(cases):
     dim = 3 if rng.random() < 0.7 else 2
