@@ -451,6 +451,12 @@ __global__ void __launch_bounds__(64 * WX * WY, 4)  // four waves per SIMD whate
     const Geo<XSplit, real> g(sx, sy);
     const int H = g.H;
     const int M = (sx + 1) >> 1;
+#ifdef MGX_DIAGNOSTICS  // TIMING ONLY (wrong results), the unrolled loop: bits 4 ... of xcd_mode switch parts of a step off (tools/pipe_ablate.py)
+    const int ABLP = xcd_mode >> 4;
+    xcd_mode &= 15;
+#else
+    constexpr int ABLP = 0;
+#endif
     unsigned b = blockIdx.x;
     if (xcd_mode == 1) {
         const unsigned nb = gridDim.x, k = b & 7u, per = nb >> 3, rem = nb & 7u;
@@ -2405,9 +2411,14 @@ static void launch_xs_lds(mgx_ctx* ctx, real* v, const real* f, int sx, int sy, 
             // the name rocprofv3 shows carries <..., VAR = 0, UNR = 1 / 2 by q0 (3 / 4: two steps ahead), CSP = 0>
             snprintf(ctx->last_relax_kernel, sizeof ctx->last_relax_kernel, "relax3d_xs_pipe_kernel<%s,%d,%d,2,%s,0,unrolled%s>", sizeof(real) == 8 ? "double" : "float",
                      WX, WY, kind == 2 && WY == 8 ? "true" : "false", (ctx->pipe_unroll & 16) ? " depth 2" : "");
+#ifdef MGX_DIAGNOSTICS
+            const int xcda = xcd | ((ctx->relax_ablate >= 100 ? ctx->relax_ablate - 100 : 0) << 4);  // "relax3d.ablate" = 100 + bits: see the kernel
+#else
+            const int xcda = xcd;
+#endif
 #define MGX_PU(F, U)                                                                                                                    \
     MGX_LAUNCH((relax3d_xs_pipe_kernel<real, WX, WY, 2, F, 0, U>), gride, block, 0, ctx->compute, (const real*)v, v, f, sx, sy, zbeg, zend, hx2, \
-               hy2, hz2, colour, zce, gx, gy, xcd)
+               hy2, hz2, colour, zce, gx, gy, xcda)
             // bit 4: DEPTH 2 (the column and f requested two steps ahead: twice the bytes in flight)
 #ifdef MGX_DIAGNOSTICS
             if (ctx->relax_ablate == 77) {  // TIMING ONLY: the access pattern of a colour-contiguous layout (wrong results)
